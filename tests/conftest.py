@@ -1,0 +1,28 @@
+import json
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+GOLDEN = ROOT / "tests" / "golden"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    return json.loads((GOLDEN / name).read_text())
+
+
+@pytest.fixture(scope="session")
+def post_cases():
+    return load_golden("post_cases.json")["cases"]
+
+
+@pytest.fixture(scope="session")
+def tracker_cases():
+    return load_golden("tracker_cases.json")

@@ -1,0 +1,115 @@
+"""The CPU oracle (oracle/rva_oracle.c) against the goldens recorded from the reference itself.
+
+These pin the oracle BEFORE it is trusted as the checker of the HIP path.
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from realtime_video_analytics_32streams_amd import synth
+from tests.conftest import load_golden
+from tests.helpers import head_for_case, script_sha, table_digest
+
+
+def _case_id(c):
+    return f"{c['kind']}-{c.get('seed', c.get('name'))}-{c.get('model_type', 'v8')}"
+
+
+@pytest.mark.parametrize("case", load_golden("post_cases.json")["cases"], ids=_case_id)
+def test_postprocess_matches_reference(case):
+    raw = head_for_case(case)
+    exp = case["expect"]
+    got = orc.postprocess(raw, case["conf"], case["iou"], case["classes"], tuple(case["orig_wh"]))
+    assert got["n"] == exp["n"]
+    assert got["n_cand"] == exp["n_cand"]
+    assert got["anchor"].tolist() == exp["anchor"]          # bit-exact box indices
+    assert got["keep"].tolist() == exp["keep"]
+    assert got["cls"].tolist() == exp["cls"]
+    # float32 values widened to Python floats by the reference: compare exactly
+    assert [float(v) for v in got["conf"]] == exp["conf"]
+    assert [[float(v) for v in b] for b in got["boxes"]] == exp["boxes"]
+
+
+def test_tracker_inline_probes(tracker_cases):
+    for probe in tracker_cases["inline"]:
+        cfg = probe["cfg"]
+        names = sorted({s["stream"] for s in probe["steps"]})
+        trk = orc.Tracker(len(names), cfg["max_age"], cfg["max_iou_distance"], cfg["min_hits"])
+        for step in probe["steps"]:
+            res = trk.update(names.index(step["stream"]), np.asarray(step["boxes"], np.float64).reshape(-1, 4),
+                             step["conf"], step["cls"])
+            assert orc.table_of(res) == step["table"], probe["name"]
+
+
+@pytest.mark.parametrize("idx", range(5))
+def test_tracker_seeded_scripts(tracker_cases, idx):
+    case = tracker_cases["seeded"][idx]
+    cfg = case["cfg"]
+    script = synth.make_tracker_script(case["seed"], case["n_streams"], case["n_ticks"], n_obj=case["n_obj"])
+    assert script_sha(script) == case["sha"], "numpy drift in the tracker script generator"
+    trk = orc.Tracker(case["n_streams"], cfg["max_age"], cfg["max_iou_distance"], cfg["min_hits"])
+    k = 0
+    last = {}
+    for t in range(case["n_ticks"]):
+        for s in range(case["n_streams"]):
+            fd = script[t][s]
+            m = fd.conf >= case["conf_thr"]          # F1 filter_detections (pipeline.py:182)
+            res = trk.update(s, fd.boxes[m], fd.conf[m], fd.cls[m])
+            tab = orc.table_of(res)
+            assert table_digest(tab) == case["digests"][k], (t, s)
+            last[f"s{s}"] = tab
+            k += 1
+    assert last == case["final"]
+
+
+def test_clip_schedule_matches_reference():
+    for c in load_golden("temporal_buffer.json"):
+        fired, ids = orc.clip_schedule(c["L"], c["stride"], c["overlap"], 120)
+        ref_a = [f for s, f in c["fired"] if s == "a"]
+        assert fired == ref_a
+        assert ids == c["clips"][:len(ref_a)]
+        # second stream buffers independently and identically
+        assert ids == c["clips"][len(ref_a):]
+
+
+def test_letterbox_meta():
+    for c in load_golden("letterbox_meta.json"):
+        m = orc.letterbox(c["w"], c["h"], c["tw"], c["th"])
+        assert m["scale"] == c["scale"] and list(m["new"]) == c["new"] and list(m["pad"]) == c["pad"]
+
+
+def test_resize_special_cases():
+    """Decimation at 3:1 and 2x2 mean at 6:1 / 2:1 (SURVEY.md P1 probed arithmetic)."""
+    rng = np.random.default_rng(0)
+    src = rng.integers(0, 256, (54, 96, 3), dtype=np.uint8)
+    out = orc.resize_linear(src, 32, 18)                      # 3:1 -> src[3y+1, 3x+1]
+    assert np.array_equal(out, src[1::3, 1::3])
+    out = orc.resize_linear(src, 48, 27)                      # 2:1 -> INTER_AREA 2x2 mean
+    s = src.astype(np.int32)
+    area = (s[0::2, 0::2] + s[0::2, 1::2] + s[1::2, 0::2] + s[1::2, 1::2] + 2) >> 2
+    assert np.array_equal(out, area.astype(np.uint8))
+    out = orc.resize_linear(src, 16, 9)                       # 6:1 -> mean of src[6y+2..3, 6x+2..3]
+    m = (s[2::6, 2::6] + s[2::6, 3::6] + s[3::6, 2::6] + s[3::6, 3::6] + 2) >> 2
+    assert np.array_equal(out, m.astype(np.uint8))
+    assert np.array_equal(orc.resize_linear(src, 96, 54), src)  # 1:1 copy
+
+
+def test_fp16_normalise_is_a_half_multiply():
+    """uint8.astype(float16) * (1/255) under NEP-50 is a binary16 multiply."""
+    v = np.arange(256, dtype=np.uint8)
+    want = v.astype(np.float16) * (1.0 / 255.0)
+    bgr = np.repeat(v[None, :, None], 3, axis=2).repeat(2, axis=0)       # 2x256 frame
+    out, meta = orc.preprocess_bgr(bgr, tw=256, th=2, half=True)
+    assert out.dtype == np.float16 and np.array_equal(out[0, 0].view(np.uint16), want.view(np.uint16))
+    out32, _ = orc.preprocess_bgr(bgr, tw=256, th=2, half=False)
+    assert np.array_equal(out32[0, 0], v.astype(np.float32) * (1.0 / 255.0))
+
+
+def test_preprocess_letterbox_layout():
+    bgr = synth.make_bgr(3, 96, 54)
+    out, meta = orc.preprocess_bgr(bgr, tw=64, th=64, half=False)
+    assert meta["pad"] == (0, 14) and abs(meta["scale"] - 2 / 3) < 1e-12
+    pad = np.float32(114) * np.float32(1.0 / 255.0)
+    assert np.all(out[:, :14] == pad) and np.all(out[:, 50:] == pad)
+    rs = orc.resize_linear(bgr, 64, 36)
+    assert np.array_equal(out[0, 14:50], rs[..., 2].astype(np.float32) * np.float32(1 / 255.0))  # R plane first
