@@ -1,0 +1,189 @@
+/*
+ * rva.h -- C ABI of librva.so: the MI355X-native detect/track hot path.
+ *
+ * Boundary: everything the reference's Detector / Tracker plugin API computes between "a decoded
+ * frame is available" and "tracks are visible to the host" (SURVEY.md section 8).  The reference is
+ * pure Python and has no FFI of its own; each entry point below names the reference function(s)
+ * it replaces (paths relative to /root/reference/src/realtime_analytics/).  Plain pointers and
+ * sizes only: no torch / Python types cross this boundary.
+ *
+ * Conventions
+ *   - `stream` is a hipStream_t passed as void*; NULL = the default stream.  All device work is
+ *     enqueued on it and nothing synchronises unless the function says so ("host-synchronous").
+ *   - "device" pointers are HIP device addresses (e.g. torch.Tensor.data_ptr()).
+ *   - Return value: RVA_OK or an error code; rva_last_error(ctx) gives the text.
+ *   - No function allocates device memory once rva_reserve()/…_create() have sized the context, so a
+ *     caller may capture a whole tick into a hipGraph.
+ *   - There is NO CPU fallback: if no HIP device is usable, rva_create() fails.
+ */
+#ifndef RVA_H
+#define RVA_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RVA_ABI_VERSION 1
+
+enum rva_status {
+    RVA_OK = 0,
+    RVA_ERR_ARG = 1,         /* bad argument / unsupported shape */
+    RVA_ERR_HIP = 2,         /* a HIP runtime call failed */
+    RVA_ERR_CAPACITY = 3,    /* a capacity given at create/reserve time was exceeded */
+    RVA_ERR_UNAVAILABLE = 4  /* optional component (rocDecode) not present on this machine */
+};
+
+enum rva_dtype { RVA_F16 = 0, RVA_F32 = 1 };
+
+typedef struct rva_ctx rva_ctx;
+typedef struct rva_tracker rva_tracker;
+typedef void *rva_stream_t;
+
+int rva_abi_version(void);
+int rva_create(int device, rva_ctx **out);
+void rva_destroy(rva_ctx *ctx);
+const char *rva_last_error(const rva_ctx *ctx);
+
+/* Pre-size every scratch buffer for `batch` images x `anchors` head rows (host-synchronous; call
+ * before graph capture).  Optional: buffers otherwise grow on first use. */
+int rva_reserve(rva_ctx *ctx, int batch, int anchors);
+
+/* ----------------------------------------------------------------------------------------------
+ * Letterbox geometry -- detector.py:209-230 and the `meta` dict of :259-263.
+ * -------------------------------------------------------------------------------------------- */
+typedef struct rva_letterbox {
+    int32_t src_w, src_h;   /* meta["orig_shape"] = (src_h, src_w) */
+    int32_t dst_w, dst_h;   /* detector input size (input_hw) */
+    int32_t new_w, new_h;   /* int(w*scale), int(h*scale) */
+    int32_t pad_left, pad_top; /* meta["pad"] */
+    double scale;           /* meta["scale"] (Python float) */
+} rva_letterbox;
+
+int rva_letterbox_meta(int src_w, int src_h, int dst_w, int dst_h, rva_letterbox *out);
+
+/* ----------------------------------------------------------------------------------------------
+ * K1 pre-process -- replaces _TensorRTBaseDetector._preprocess (detector.py:198-264) for a whole
+ * tick of frames in ONE launch: [colour convert] -> cv2.resize(INTER_LINEAR) letterbox -> pad 114
+ * -> BGR2RGB -> astype(dtype) * (1/255) -> CHW, written straight into the batch tensor
+ * out[n, 3, dst_h, dst_w] (device).  n <= RVA_MAX_BATCH per call.
+ *
+ * nv12: y_ptrs[i] / uv_ptrs[i] are device pointers of pitch-linear NV12 surfaces (what a hardware
+ *       decoder hands over instead of video_stream.py:173's BGR ndarray); BT.601 limited range,
+ *       nearest chroma, converted at full resolution before the resize, as FFmpeg+OpenCV would.
+ * bgr:  frames[i] is a device copy of the uint8 [src_h, src_w, 3] BGR frame of FramePacket.frame.
+ * meta_out (host, may be NULL) receives the geometry shared by all n frames.
+ * -------------------------------------------------------------------------------------------- */
+#define RVA_MAX_BATCH 64
+
+int rva_preprocess_nv12_batch(rva_ctx *ctx, const void *const *y_ptrs, const void *const *uv_ptrs,
+                              const int32_t *pitches, int n, int src_w, int src_h, void *out,
+                              int out_dtype, int dst_w, int dst_h, rva_letterbox *meta_out,
+                              rva_stream_t stream);
+
+int rva_preprocess_bgr_batch(rva_ctx *ctx, const void *const *frames, const int32_t *row_bytes, int n,
+                             int src_w, int src_h, void *out, int out_dtype, int dst_w, int dst_h,
+                             rva_letterbox *meta_out, rva_stream_t stream);
+
+/* Clip-frame pre-process -- replaces the per-frame body of CNNLSTMDetector._preprocess_sequence
+ * (temporal_detector.py:340-359): stretch-resize to (dst_w, dst_h), BGR2RGB, /255.0, (x-mean)/std
+ * (ImageNet constants), CHW; out[n, 3, dst_h, dst_w] in out_dtype (float32 math, cast last). */
+int rva_preprocess_clip_nv12_batch(rva_ctx *ctx, const void *const *y_ptrs, const void *const *uv_ptrs,
+                                   const int32_t *pitches, int n, int src_w, int src_h, void *out,
+                                   int out_dtype, int dst_w, int dst_h, rva_stream_t stream);
+
+int rva_preprocess_clip_bgr_batch(rva_ctx *ctx, const void *const *frames, const int32_t *row_bytes,
+                                  int n, int src_w, int src_h, void *out, int out_dtype, int dst_w,
+                                  int dst_h, rva_stream_t stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * K2+K3 post-process -- replaces _TensorRTBaseDetector._postprocess with _xywh2xyxy, _scale_boxes,
+ * _nms and module _iou (detector.py:266-375, 469-481) for a batch of head tensors.
+ *
+ * raw: device, [batch, d1, d2] contiguous, float16 or float32 (float16 is widened exactly).  Each
+ *      image is oriented like detector.py:282-283: d1 < d2 means [channels, anchors], otherwise
+ *      [anchors, channels].  channels < 5 -> every count is 0 (detector.py:285-287).
+ * metas: host array of `batch` geometries (or 1 entry broadcast when n_metas == 1).
+ * classes: host array (config.classes) or NULL.
+ * Outputs (device), per image b in NMS order (descending score; ties: ascending anchor):
+ *   out_boxes[b][i][4] xyxy frame pixels, out_scores[b][i], out_cls[b][i],
+ *   out_anchor[b][i]  anchor row of the detection, out_cand[b][i] its index among the thresholded
+ *   candidates (the value the reference's `keep` list holds), out_counts[b], out_ncand[b].
+ *   Arrays are [batch, max_det]; out_anchor/out_cand/out_ncand may be NULL.
+ * The reference has no detection cap: pass max_det = anchors for exact behaviour; if an image keeps
+ * more than max_det boxes the extra ones are dropped and bit 0 of rva_post_status() is set.
+ * -------------------------------------------------------------------------------------------- */
+int rva_postprocess_batch(rva_ctx *ctx, const void *raw, int raw_dtype, int batch, int d1, int d2,
+                          double conf_thr, double iou_thr, const int32_t *classes, int n_classes,
+                          const rva_letterbox *metas, int n_metas, int max_det, float *out_boxes,
+                          float *out_scores, int32_t *out_cls, int32_t *out_anchor, int32_t *out_cand,
+                          int32_t *out_counts, int32_t *out_ncand, rva_stream_t stream);
+
+/* Host-synchronous: bit 0 = max_det overflow, bit 1 = candidate capacity overflow since the last call. */
+int rva_post_status(rva_ctx *ctx, rva_stream_t stream, int *flags);
+
+/* ----------------------------------------------------------------------------------------------
+ * K4 tracker -- replaces IouTracker (tracker.py:45-147) for all streams of this process.
+ *
+ * One table per stream lives in HBM (structure-of-arrays, `capacity` rows, insertion order ==
+ * the reference's dict order).  An update tick processes any subset of streams concurrently (one
+ * wavefront per stream; the per-detection greedy loop of tracker.py:55-92 stays sequential inside
+ * it), then rva_tracker_assign_ids() hands out the reference's GLOBAL ids (tracker.py:47) in the
+ * canonical order "stream-minor within the tick".
+ * -------------------------------------------------------------------------------------------- */
+int rva_tracker_create(rva_ctx *ctx, int n_streams, int capacity, int max_age, double max_iou_distance,
+                       int min_hits, rva_tracker **out);
+void rva_tracker_destroy(rva_tracker *trk);
+
+/* Detections straight from rva_postprocess_batch (device, float32, [batch, max_det] layout).
+ * slot_of_stream: host int32[n_streams]; entry s = batch row holding stream s's detections this
+ * tick, or -1 if stream s has no frame this tick (its table is untouched), or -2 for a skipped
+ * frame (update(name, []) of pipeline.py:215: ages every track).
+ * filter_thr: filter_detections' threshold (pipeline.py:182), applied on the widened score. */
+int rva_tracker_update_f32(rva_tracker *trk, const int32_t *slot_of_stream, const float *boxes,
+                           const float *scores, const int32_t *cls, const int32_t *counts, int max_det,
+                           double filter_thr, rva_stream_t stream);
+
+/* Detections supplied by the host API (IouTracker.update(stream_name, detections)): device arrays
+ * double boxes[total][4], double conf[total], int64 cls[total]; stream s owns rows
+ * [offsets[s], offsets[s+1]) when active[s] != 0 (host arrays, n_streams(+1) entries). */
+int rva_tracker_update_f64(rva_tracker *trk, const int32_t *active, const int32_t *offsets,
+                           const double *boxes, const double *conf, const int64_t *cls,
+                           rva_stream_t stream);
+
+/* Device address of int32 new_counts[n_streams] written by the last update (for the multi-GPU
+ * all-gather of SURVEY.md 8e). */
+int32_t *rva_tracker_new_counts(rva_tracker *trk);
+
+/* Give final ids to the tracks created by the last update.  counts_all: device int32[n_global] =
+ * new-track counts of ALL streams of the job in canonical order (NULL: this process owns every
+ * stream; uses its own new_counts).  global_index: host int32[n_streams] position of each local
+ * stream in that order (NULL: identity).  Advances the id counter by sum(counts_all). */
+int rva_tracker_assign_ids(rva_tracker *trk, const int32_t *counts_all, int n_global,
+                           const int32_t *global_index, rva_stream_t stream);
+
+/* Host-synchronous read-back of one stream's table in insertion order (Track fields of
+ * tracker.py:18-27).  Returns the row count in *n (rows beyond `cap` are not copied). */
+int rva_tracker_read(rva_tracker *trk, int stream_id, int cap, int64_t *ids, int32_t *cls, int32_t *age,
+                     int32_t *hits, double *conf, double *boxes, int32_t *n, rva_stream_t stream);
+
+/* Host-synchronous read-back of every stream at once: arrays are [n_streams, capacity(,4)],
+ * counts[n_streams]; any pointer may be NULL. */
+int rva_tracker_read_all(rva_tracker *trk, int64_t *ids, int32_t *cls, int32_t *age, int32_t *hits,
+                         double *conf, double *boxes, int32_t *counts, rva_stream_t stream);
+
+/* Host-synchronous: next id the counter will hand out; flags bit 0 = a table overflowed `capacity`. */
+int rva_tracker_state(rva_tracker *trk, int64_t *next_id, int *flags, rva_stream_t stream);
+int rva_tracker_set_next_id(rva_tracker *trk, int64_t next_id, rva_stream_t stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * Decode probe -- stands where VideoStream.open() (video_stream.py:61-95) sits.  librocdecode is
+ * looked up with dlopen at run time; RVA_ERR_UNAVAILABLE if the machine does not have it.
+ * -------------------------------------------------------------------------------------------- */
+int rva_decode_available(char *detail, int detail_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RVA_H */

@@ -1,0 +1,64 @@
+// Internal definitions shared by the librva translation units (not part of the C ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "rva.h"
+
+struct rva_resize_table {  // device copy of the per-axis resize taps for one geometry
+    int32_t *ofs = nullptr;   // [n]   first source index
+    int16_t *w0 = nullptr;    // [n]   11-bit fixed-point weight of tap 0
+    int16_t *w1 = nullptr;    // [n]   ... of tap 1
+    int n = 0;
+};
+
+struct rva_geom_cache {
+    rva_resize_table x, y;
+};
+
+struct rva_ctx {
+    int device = 0;
+    std::string err;
+    // post-process scratch, sized by rva_reserve / grown on demand
+    int cap_batch = 0, cap_anchors = 0;
+    float *sp_box = nullptr;      // [B][A][4] xyxy of thresholded anchors (sparse, anchor-indexed)
+    float *sp_score = nullptr;    // [B][A]
+    int32_t *sp_cls = nullptr;    // [B][A]
+    int32_t *cand_list = nullptr; // [B][A] anchors that passed, unordered
+    int32_t *cand_count = nullptr;// [B]
+    uint32_t *cand_bits = nullptr;// [B][ceil(A/32)] pass bitmap in anchor order
+    int32_t *post_flags = nullptr;// [1]
+    // resize tap tables keyed by (src, dst) per axis
+    std::map<uint64_t, rva_resize_table> taps_x, taps_y;
+};
+
+inline int rva_fail(rva_ctx *ctx, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    return code;
+}
+
+#define RVA_HIP(ctx, call)                                                                          \
+    do {                                                                                            \
+        hipError_t e_ = (call);                                                                     \
+        if (e_ != hipSuccess)                                                                       \
+            return rva_fail((ctx), RVA_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                            __FILE__, __LINE__);                                                    \
+    } while (0)
+
+// Host restatement of the OpenCV resize tap computation; fills a device table (cached in ctx).
+int rva_get_taps(rva_ctx *ctx, int src, int dst, bool is_x, rva_resize_table *out);
+
+static inline int rva_ceil_div(int a, int b) { return (a + b - 1) / b; }

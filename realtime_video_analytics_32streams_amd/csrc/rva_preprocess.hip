@@ -1,0 +1,342 @@
+// K1: fused pre-process for a whole tick of frames in one launch.
+//
+// Replaces _TensorRTBaseDetector._preprocess (detector.py:198-264) and the per-frame body of
+// CNNLSTMDetector._preprocess_sequence (temporal_detector.py:340-359):
+//   [NV12 -> BGR, BT.601 limited, nearest chroma: what FFmpeg/OpenCV would have handed over]
+//   -> cv2.resize INTER_LINEAR (OpenCV's 11-bit fixed-point taps, bit-exact integer arithmetic)
+//   -> letterbox pad 114 -> BGR2RGB -> astype(dtype) * (1/255) (binary16 multiply when half)
+//   -> planar CHW written straight into the batch tensor.
+// The colour conversion is applied to each TAP before interpolation (convert-then-resize), which is
+// the reference's order; only the tapped pixels are converted.
+//
+// Two kernels:
+//   k1_ratio<R>   source = R x letterboxed content (R integer: 1080p->640 is R=3, 4K is R=6, 720p
+//                 R=2): the taps are src[R*y + (R-1)/2] (odd R, fraction 0) or the 2x2 block at
+//                 R*y + R/2 - 1 (even R, fraction 1/2 => (a+b+c+d+2)>>2 in OpenCV's fixed point).
+//                 Each lane owns 8 output pixels = 8R contiguous source bytes per plane row, loaded as
+//                 R aligned 8-byte words (lanes contiguous => whole rows stream through once), and
+//                 stores one 16-byte (fp16) vector per colour plane.
+//   k1_generic    any geometry / BGR frames / clip (stretch + mean/std) epilogue: per-pixel taps from
+//                 the tap tables (host-computed exactly like OpenCV, cached on the device).
+#include <hip/hip_fp16.h>
+
+#include "rva_internal.h"
+
+namespace {
+
+struct K1Args {
+    const uint8_t *p0[RVA_MAX_BATCH];  // Y plane (NV12) or BGR frame
+    const uint8_t *p1[RVA_MAX_BATCH];  // interleaved UV plane (NV12)
+    int32_t pitch[RVA_MAX_BATCH];      // bytes per row
+    int src_w, src_h, dst_w, dst_h, new_w, new_h, left, top;
+    const int32_t *xofs; const int16_t *xw0, *xw1;
+    const int32_t *yofs; const int16_t *yw0, *yw1;
+    void *out;
+};
+
+__device__ __forceinline__ int clip8(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+
+// BT.601 limited-range integer matrix (D1 stand-in, see oracle/rva_oracle.c orc_yuv_to_bgr)
+__device__ __forceinline__ void yuv2bgr(int Y, int U, int V, int &b, int &g, int &r)
+{
+    const int c = 298 * (Y - 16), d = U - 128, e = V - 128;
+    b = clip8((c + 516 * d + 128) >> 8);
+    g = clip8((c - 100 * d - 208 * e + 128) >> 8);
+    r = clip8((c + 409 * e + 128) >> 8);
+}
+
+// ---- epilogues -------------------------------------------------------------------------------
+constexpr unsigned short kInv255Half = 0x1C04;  // float16(1/255): NEP-50 casts the python float directly
+
+template <typename OutT> struct Vec8;
+template <> struct Vec8<__half> { uint4 v; };
+template <> struct Vec8<float> { float4 lo, hi; };
+
+// detector.py:248-251: uint8.astype(dtype) * (1.0/255.0)
+__device__ __forceinline__ __half norm_yolo(int v, __half) { return __hmul(__int2half_rn(v), __ushort_as_half(kInv255Half)); }
+__device__ __forceinline__ float norm_yolo(int v, float) { return (float)v * (float)(1.0 / 255.0); }
+
+// temporal_detector.py:350-354: float32 /255.0 then (x-mean)/std, cast last (:368-371)
+__device__ __forceinline__ float norm_clip32(int v, int c)
+{
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+    float x = __fdiv_rn((float)v, 255.0f);
+    return __fdiv_rn(x - mean[c], stdv[c]);
+}
+__device__ __forceinline__ __half norm_clip(int v, int c, __half) { return __float2half_rn(norm_clip32(v, c)); }
+__device__ __forceinline__ float norm_clip(int v, int c, float) { return norm_clip32(v, c); }
+
+template <typename OutT>
+__device__ __forceinline__ void store8(OutT *dst, const OutT *v, bool vec_ok, int nvalid)
+{
+    if (vec_ok && nvalid == 8) {
+        if constexpr (sizeof(OutT) == 2) {
+            *reinterpret_cast<uint4 *>(dst) = *reinterpret_cast<const uint4 *>(v);
+        } else {
+            reinterpret_cast<float4 *>(dst)[0] = reinterpret_cast<const float4 *>(v)[0];
+            reinterpret_cast<float4 *>(dst)[1] = reinterpret_cast<const float4 *>(v)[1];
+        }
+    } else {
+        for (int i = 0; i < nvalid; ++i) dst[i] = v[i];
+    }
+}
+
+// ---- integer-ratio fast path -----------------------------------------------------------------
+template <int R, typename OutT>
+__global__ void __launch_bounds__(256) k1_ratio(K1Args a)
+{
+    const int img = blockIdx.y;
+    const int groups = a.dst_w >> 3;
+    const int item = blockIdx.x * 256 + threadIdx.x;
+    if (item >= groups * a.dst_h) return;
+    const int oy = item / groups, xg = item - oy * groups;
+    const int ox = xg << 3;
+    const size_t plane = (size_t)a.dst_w * a.dst_h;
+    OutT *out = (OutT *)a.out + (size_t)img * 3 * plane + (size_t)oy * a.dst_w + ox;
+    alignas(16) OutT vr[8], vg[8], vb[8];
+    const int cy = oy - a.top, cx = ox - a.left;
+    if (cy < 0 || cy >= a.new_h || cx < 0 || cx >= a.new_w) {  // letterbox border (detector.py:233-241)
+        const OutT p = norm_yolo(114, OutT());
+#pragma unroll
+        for (int i = 0; i < 8; ++i) vr[i] = vg[i] = vb[i] = p;
+    } else {
+        const uint8_t *yp = a.p0[img];
+        const uint8_t *uvp = a.p1[img];
+        const int pitch = a.pitch[img];
+        constexpr int NW = R;          // 8-byte words per 8 output pixels
+        constexpr bool ODD = (R & 1) != 0;
+        constexpr int ROWS = ODD ? 1 : 2;
+        const int sy0 = ODD ? R * cy + (R - 1) / 2 : R * cy + R / 2 - 1;
+        const size_t xoff = (size_t)R * cx;  // multiple of 8
+        uint2 yw[ROWS][NW], uw[ROWS][NW];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const uint2 *ys = reinterpret_cast<const uint2 *>(yp + (size_t)(sy0 + r) * pitch + xoff);
+            const uint2 *us = reinterpret_cast<const uint2 *>(uvp + (size_t)((sy0 + r) >> 1) * pitch + xoff);
+#pragma unroll
+            for (int k = 0; k < NW; ++k) { yw[r][k] = ys[k]; uw[r][k] = us[k]; }
+        }
+        auto byte_at = [](const uint2 *w, int o) -> int {
+            const uint32_t d = (o & 4) ? w[o >> 3].y : w[o >> 3].x;
+            return (int)((d >> ((o & 3) * 8)) & 0xffu);
+        };
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            int b, g, r;
+            if constexpr (ODD) {
+                const int o = R * i + (R - 1) / 2;
+                const int uo = (o >> 1) << 1;
+                yuv2bgr(byte_at(yw[0], o), byte_at(uw[0], uo), byte_at(uw[0], uo + 1), b, g, r);
+            } else {
+                int sb = 2, sg = 2, sr = 2;  // (a + b + c + d + 2) >> 2
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                    for (int cc = 0; cc < 2; ++cc) {
+                        const int o = R * i + R / 2 - 1 + cc;
+                        const int uo = (o >> 1) << 1;
+                        int tb, tg, tr;
+                        yuv2bgr(byte_at(yw[rr], o), byte_at(uw[rr], uo), byte_at(uw[rr], uo + 1), tb, tg, tr);
+                        sb += tb; sg += tg; sr += tr;
+                    }
+                b = sb >> 2; g = sg >> 2; r = sr >> 2;
+            }
+            vr[i] = norm_yolo(r, OutT()); vg[i] = norm_yolo(g, OutT()); vb[i] = norm_yolo(b, OutT());
+        }
+    }
+    store8<OutT>(out, vr, true, 8);              // R plane first (BGR2RGB, detector.py:245)
+    store8<OutT>(out + plane, vg, true, 8);
+    store8<OutT>(out + 2 * plane, vb, true, 8);
+}
+
+// ---- general path ----------------------------------------------------------------------------
+template <bool NV12, bool CLIP, typename OutT>
+__global__ void __launch_bounds__(256) k1_generic(K1Args a)
+{
+    const int img = blockIdx.y;
+    const int groups = (a.dst_w + 7) >> 3;
+    const int item = blockIdx.x * 256 + threadIdx.x;
+    if (item >= groups * a.dst_h) return;
+    const int oy = item / groups, xg = item - oy * groups;
+    const int ox = xg << 3;
+    const int nvalid = a.dst_w - ox < 8 ? a.dst_w - ox : 8;
+    const size_t plane = (size_t)a.dst_w * a.dst_h;
+    OutT *out = (OutT *)a.out + (size_t)img * 3 * plane + (size_t)oy * a.dst_w + ox;
+    alignas(16) OutT vr[8], vg[8], vb[8];
+    const uint8_t *p0 = a.p0[img];
+    const uint8_t *p1 = a.p1[img];
+    const int pitch = a.pitch[img];
+    const int cy = oy - a.top;
+    const bool row_in = cy >= 0 && cy < a.new_h;
+    int sy0 = 0, sy1 = 0, wb0 = 0, wb1 = 0;
+    if (row_in) {
+        const int s = a.yofs[cy];
+        sy0 = min(max(s, 0), a.src_h - 1);       // resizeGeneric_Invoker row clip
+        sy1 = min(max(s + 1, 0), a.src_h - 1);
+        wb0 = a.yw0[cy]; wb1 = a.yw1[cy];
+    }
+    auto fetch = [&](int sy, int sx, int &b, int &g, int &r) {
+        if constexpr (NV12) {
+            const int Y = p0[(size_t)sy * pitch + sx];
+            const uint8_t *u = p1 + (size_t)(sy >> 1) * pitch + ((sx >> 1) << 1);
+            yuv2bgr(Y, u[0], u[1], b, g, r);
+        } else {
+            const uint8_t *p = p0 + (size_t)sy * pitch + (size_t)sx * 3;
+            b = p[0]; g = p[1]; r = p[2];
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int b = 114, g = 114, r = 114;
+        const int cx = ox + i - a.left;
+        if (row_in && cx >= 0 && cx < a.new_w && i < nvalid) {
+            const int sx0 = a.xofs[cx];
+            const int sx1 = min(sx0 + 1, a.src_w - 1);
+            const int wa0 = a.xw0[cx], wa1 = a.xw1[cx];
+            int b00, g00, r00, b01 = 0, g01 = 0, r01 = 0, b10 = 0, g10 = 0, r10 = 0, b11 = 0, g11 = 0, r11 = 0;
+            fetch(sy0, sx0, b00, g00, r00);
+            if (wa1) fetch(sy0, sx1, b01, g01, r01);
+            if (wb1) {
+                fetch(sy1, sx0, b10, g10, r10);
+                if (wa1) fetch(sy1, sx1, b11, g11, r11);
+            }
+            // HResizeLinear: S0*a0 + S1*a1 ; VResizeLinear: ((b0*(H0>>4))>>16) + ((b1*(H1>>4))>>16) + 2 >> 2
+            auto mix = [&](int s00, int s01, int s10, int s11) {
+                const int h0 = s00 * wa0 + s01 * wa1, h1 = s10 * wa0 + s11 * wa1;
+                return clip8((((wb0 * (h0 >> 4)) >> 16) + ((wb1 * (h1 >> 4)) >> 16) + 2) >> 2);
+            };
+            b = mix(b00, b01, b10, b11); g = mix(g00, g01, g10, g11); r = mix(r00, r01, r10, r11);
+        }
+        if constexpr (CLIP) {
+            vr[i] = norm_clip(r, 0, OutT()); vg[i] = norm_clip(g, 1, OutT()); vb[i] = norm_clip(b, 2, OutT());
+        } else {
+            vr[i] = norm_yolo(r, OutT()); vg[i] = norm_yolo(g, OutT()); vb[i] = norm_yolo(b, OutT());
+        }
+    }
+    const bool vec_ok = (a.dst_w & 7) == 0;
+    store8<OutT>(out, vr, vec_ok, nvalid);
+    store8<OutT>(out + plane, vg, vec_ok, nvalid);
+    store8<OutT>(out + 2 * plane, vb, vec_ok, nvalid);
+}
+
+template <typename OutT>
+bool launch_ratio(int R, dim3 grid, hipStream_t s, const K1Args &a)
+{
+    switch (R) {
+        case 1: k1_ratio<1, OutT><<<grid, 256, 0, s>>>(a); return true;
+        case 2: k1_ratio<2, OutT><<<grid, 256, 0, s>>>(a); return true;
+        case 3: k1_ratio<3, OutT><<<grid, 256, 0, s>>>(a); return true;
+        case 4: k1_ratio<4, OutT><<<grid, 256, 0, s>>>(a); return true;
+        case 6: k1_ratio<6, OutT><<<grid, 256, 0, s>>>(a); return true;
+        default: return false;
+    }
+}
+
+int preprocess_common(rva_ctx *ctx, bool nv12, bool clip, const void *const *p0, const void *const *p1,
+                      const int32_t *pitches, int n, int src_w, int src_h, void *out, int out_dtype, int dst_w,
+                      int dst_h, rva_letterbox *meta_out, hipStream_t stream)
+{
+    if (!ctx) return RVA_ERR_ARG;
+    if (!p0 || (nv12 && !p1) || !pitches || n <= 0 || n > RVA_MAX_BATCH || !out || src_w <= 0 || src_h <= 0 ||
+        dst_w <= 0 || dst_h <= 0)
+        return rva_fail(ctx, RVA_ERR_ARG, "preprocess: bad argument (1 <= n <= %d)", RVA_MAX_BATCH);
+    if (out_dtype != RVA_F16 && out_dtype != RVA_F32) return rva_fail(ctx, RVA_ERR_ARG, "out_dtype must be RVA_F16|RVA_F32");
+    if (nv12 && ((src_w | src_h) & 1)) return rva_fail(ctx, RVA_ERR_ARG, "NV12 surfaces need even dimensions");
+    rva_letterbox m;
+    if (clip) {  // stretch to the full target (temporal_detector.py:344), no border
+        m.src_w = src_w; m.src_h = src_h; m.dst_w = dst_w; m.dst_h = dst_h; m.new_w = dst_w; m.new_h = dst_h;
+        m.pad_left = m.pad_top = 0; m.scale = 0.0;
+    } else if (rva_letterbox_meta(src_w, src_h, dst_w, dst_h, &m) != RVA_OK) {
+        return rva_fail(ctx, RVA_ERR_ARG, "bad geometry");
+    }
+    if (m.new_w <= 0 || m.new_h <= 0) return rva_fail(ctx, RVA_ERR_ARG, "frame too thin for this input size");
+    if (meta_out) *meta_out = m;
+
+    K1Args a{};
+    bool aligned8 = true;
+    for (int i = 0; i < n; ++i) {
+        a.p0[i] = (const uint8_t *)p0[i];
+        a.p1[i] = nv12 ? (const uint8_t *)p1[i] : nullptr;
+        a.pitch[i] = pitches[i];
+        if (!p0[i] || (nv12 && !p1[i]) || pitches[i] < (nv12 ? src_w : 3 * src_w))
+            return rva_fail(ctx, RVA_ERR_ARG, "preprocess: surface %d has a null plane or a short pitch", i);
+        aligned8 = aligned8 && ((uintptr_t)p0[i] % 8 == 0) && (!nv12 || (uintptr_t)p1[i] % 8 == 0) && pitches[i] % 8 == 0;
+    }
+    a.src_w = src_w; a.src_h = src_h; a.dst_w = dst_w; a.dst_h = dst_h;
+    a.new_w = m.new_w; a.new_h = m.new_h; a.left = m.pad_left; a.top = m.pad_top;
+    a.out = out;
+    const size_t osz = out_dtype == RVA_F16 ? 2 : 4;
+    const bool out_aligned = ((uintptr_t)out % 16 == 0) && ((dst_w * osz) % 16 == 0);
+
+    // integer-ratio fast path
+    const int R = src_w / m.new_w;
+    const bool ratio_ok = nv12 && !clip && aligned8 && out_aligned && R * m.new_w == src_w && R * m.new_h == src_h &&
+                          (dst_w % 8 == 0) && (m.new_w % 8 == 0) && (m.pad_left % 8 == 0);
+    if (ratio_ok) {
+        dim3 grid(rva_ceil_div((dst_w / 8) * dst_h, 256), n);
+        const bool ok = out_dtype == RVA_F16 ? launch_ratio<__half>(R, grid, stream, a) : launch_ratio<float>(R, grid, stream, a);
+        if (ok) {
+            RVA_HIP(ctx, hipGetLastError());
+            return RVA_OK;
+        }
+    }
+    rva_resize_table tx, ty;
+    int rc = rva_get_taps(ctx, src_w, m.new_w, true, &tx);
+    if (rc != RVA_OK) return rc;
+    rc = rva_get_taps(ctx, src_h, m.new_h, false, &ty);
+    if (rc != RVA_OK) return rc;
+    a.xofs = tx.ofs; a.xw0 = tx.w0; a.xw1 = tx.w1;
+    a.yofs = ty.ofs; a.yw0 = ty.w0; a.yw1 = ty.w1;
+    if (!out_aligned && (dst_w % 8 == 0))  // vector stores need 16-byte rows
+        return rva_fail(ctx, RVA_ERR_ARG, "output tensor must be 16-byte aligned");
+    dim3 grid(rva_ceil_div(rva_ceil_div(dst_w, 8) * dst_h, 256), n);
+#define RVA_LAUNCH_GENERIC(NV, CL)                                                         \
+    do {                                                                                   \
+        if (out_dtype == RVA_F16) k1_generic<NV, CL, __half><<<grid, 256, 0, stream>>>(a); \
+        else k1_generic<NV, CL, float><<<grid, 256, 0, stream>>>(a);                       \
+    } while (0)
+    if (nv12 && clip) RVA_LAUNCH_GENERIC(true, true);
+    else if (nv12) RVA_LAUNCH_GENERIC(true, false);
+    else if (clip) RVA_LAUNCH_GENERIC(false, true);
+    else RVA_LAUNCH_GENERIC(false, false);
+#undef RVA_LAUNCH_GENERIC
+    RVA_HIP(ctx, hipGetLastError());
+    return RVA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rva_preprocess_nv12_batch(rva_ctx *ctx, const void *const *y_ptrs, const void *const *uv_ptrs,
+                              const int32_t *pitches, int n, int src_w, int src_h, void *out, int out_dtype,
+                              int dst_w, int dst_h, rva_letterbox *meta_out, rva_stream_t stream)
+{
+    return preprocess_common(ctx, true, false, y_ptrs, uv_ptrs, pitches, n, src_w, src_h, out, out_dtype, dst_w, dst_h,
+                             meta_out, (hipStream_t)stream);
+}
+
+int rva_preprocess_bgr_batch(rva_ctx *ctx, const void *const *frames, const int32_t *row_bytes, int n, int src_w,
+                             int src_h, void *out, int out_dtype, int dst_w, int dst_h, rva_letterbox *meta_out,
+                             rva_stream_t stream)
+{
+    return preprocess_common(ctx, false, false, frames, nullptr, row_bytes, n, src_w, src_h, out, out_dtype, dst_w, dst_h,
+                             meta_out, (hipStream_t)stream);
+}
+
+int rva_preprocess_clip_nv12_batch(rva_ctx *ctx, const void *const *y_ptrs, const void *const *uv_ptrs,
+                                   const int32_t *pitches, int n, int src_w, int src_h, void *out, int out_dtype,
+                                   int dst_w, int dst_h, rva_stream_t stream)
+{
+    return preprocess_common(ctx, true, true, y_ptrs, uv_ptrs, pitches, n, src_w, src_h, out, out_dtype, dst_w, dst_h,
+                             nullptr, (hipStream_t)stream);
+}
+
+int rva_preprocess_clip_bgr_batch(rva_ctx *ctx, const void *const *frames, const int32_t *row_bytes, int n, int src_w,
+                                  int src_h, void *out, int out_dtype, int dst_w, int dst_h, rva_stream_t stream)
+{
+    return preprocess_common(ctx, false, true, frames, nullptr, row_bytes, n, src_w, src_h, out, out_dtype, dst_w, dst_h,
+                             nullptr, (hipStream_t)stream);
+}
+
+}  // extern "C"

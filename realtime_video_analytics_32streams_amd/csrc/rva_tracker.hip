@@ -1,0 +1,435 @@
+// K4: IoU tracker for all streams of a process (replaces tracker.py:45-147).
+//
+// Layout in HBM: one structure-of-arrays table per stream, `cap` rows, row order == the reference's
+// dict insertion order (ids are handed out monotonically, so it is also ascending-id order).
+//
+// k4_update: one wavefront per stream.  The table is staged in LDS; detections are consumed in
+// order (tracker.py:55) because each one may create a track that the next one can match and may
+// overwrite the box a later one is compared against.  Per detection the 64 lanes
+// stride over the live tracks computing float64 IoU (tracker.py:129-147), then a wave reduction
+// picks the maximum IoU with the earliest row on ties -- exactly what the reference's
+// `iou >= thr and iou > best_iou` scan in dict order yields.  Pruning (tracker.py:111-126) is a
+// ballot/popcount stable compaction written back to HBM.
+// New tracks get provisional ids -(k+1); k4_assign_ids turns them into the reference's global
+// counter values in canonical order (tick-major, stream-minor), using the new-track counts of ALL
+// streams of the job (all-gathered over RCCL when streams are sharded across GPUs).
+#include <climits>
+#include <cstring>
+
+#include "rva_internal.h"
+
+#define RVA_MAX_TRACKER_STREAMS 512
+
+struct rva_tracker {
+    rva_ctx *ctx = nullptr;
+    int n_streams = 0, cap = 0, max_age = 0, min_hits = 0;
+    double min_iou = 0.0;
+    // device state
+    int64_t *id = nullptr;     // [S][cap]
+    double *box = nullptr;     // [S][cap][4]
+    double *conf = nullptr;    // [S][cap]
+    int32_t *cls = nullptr;    // [S][cap]
+    int32_t *age = nullptr;    // [S][cap]
+    int32_t *hits = nullptr;   // [S][cap]
+    int32_t *n_tracks = nullptr;  // [S]
+    int32_t *n_new = nullptr;     // [S]
+    int64_t *next_id = nullptr;   // [1]
+    int32_t *flags = nullptr;     // [1]
+    int32_t *d_slot = nullptr;    // [S] per-tick: slot / active
+    int32_t *d_offs = nullptr;    // [S+1]
+    int32_t *d_gidx = nullptr;    // [S]
+    // pinned host staging
+    int32_t *h_slot = nullptr, *h_offs = nullptr;
+    void *h_read = nullptr;
+    size_t h_read_bytes = 0;
+    hipEvent_t staged = nullptr;  // completion of the last async copy out of h_slot/h_offs
+    std::vector<int32_t> gidx_cached;
+};
+
+namespace {
+
+struct K4Args {
+    int64_t *id; double *box; double *conf; int32_t *cls, *age, *hits, *n_tracks, *n_new, *flags;
+    int cap, max_age, min_hits;
+    double min_iou;
+    const int32_t *slot;  // f64 path: device [S] active flags (staged); f32 path: unused
+    int32_t kslot[RVA_MAX_TRACKER_STREAMS];  // f32 path: batch row, -1 idle, -2 skipped frame (kernarg-resident:
+                                             // no staging buffer to race with, and graph-capturable)
+    // f32 source (post-process outputs)
+    const float4 *boxes32; const float *scores32; const int32_t *cls32; const int32_t *counts32; int max_det;
+    double filter_thr;
+    // f64 source (host API)
+    const int32_t *offs; const double *boxes64; const double *conf64; const int64_t *cls64;
+};
+
+// tracker.py:129-147, float64; a = track, b = detection
+__device__ __forceinline__ double iou64(const double a0, const double a1, const double a2, const double a3,
+                                        const double b0, const double b1, const double b2, const double b3)
+{
+    const double ix1 = a0 > b0 ? a0 : b0, iy1 = a1 > b1 ? a1 : b1;
+    const double ix2 = a2 < b2 ? a2 : b2, iy2 = a3 < b3 ? a3 : b3;
+    double iw = ix2 - ix1, ih = iy2 - iy1;
+    iw = iw > 0.0 ? iw : 0.0;
+    ih = ih > 0.0 ? ih : 0.0;
+    const double inter = iw * ih;
+    double aw = a2 - a0, ah = a3 - a1, bw = b2 - b0, bh = b3 - b1;
+    aw = aw > 0.0 ? aw : 0.0; ah = ah > 0.0 ? ah : 0.0;
+    bw = bw > 0.0 ? bw : 0.0; bh = bh > 0.0 ? bh : 0.0;
+    const double area_a = aw * ah, area_b = bw * bh;
+    const double uni = area_a + area_b - inter;
+    if (uni <= 0.0) return 0.0;
+    return __ddiv_rn(inter, uni);
+}
+
+extern __shared__ __attribute__((aligned(16))) unsigned char k4_smem[];
+
+template <bool F64SRC>
+__global__ void __launch_bounds__(64) k4_update(K4Args a)
+{
+    const int s = blockIdx.x, lane = threadIdx.x;
+    const int slot = F64SRC ? a.slot[s] : a.kslot[s];
+    if (F64SRC ? slot == 0 : slot == -1) {  // stream not updated this tick
+        if (lane == 0) a.n_new[s] = 0;
+        return;
+    }
+    const int cap = a.cap;
+    double *l_box = (double *)k4_smem;                 // [4][cap]  (component-major: conflict-free)
+    double *l_conf = l_box + 4 * (size_t)cap;          // [cap]
+    int64_t *l_id = (int64_t *)(l_conf + cap);         // [cap]
+    int32_t *l_cls = (int32_t *)(l_id + cap);          // [cap]
+    int32_t *l_age = l_cls + cap;
+    int32_t *l_hits = l_age + cap;
+    int32_t *l_match = l_hits + cap;
+
+    const size_t tb = (size_t)s * cap;
+    int n = a.n_tracks[s];
+    for (int k = lane; k < n; k += 64) {
+        const double *gb = a.box + (tb + k) * 4;
+        l_box[k] = gb[0]; l_box[cap + k] = gb[1]; l_box[2 * cap + k] = gb[2]; l_box[3 * cap + k] = gb[3];
+        l_conf[k] = a.conf[tb + k];
+        l_id[k] = a.id[tb + k];
+        l_cls[k] = a.cls[tb + k];
+        l_age[k] = a.age[tb + k];
+        l_hits[k] = a.hits[tb + k];
+        l_match[k] = 0;
+    }
+    __syncthreads();
+
+    int D = 0, d0 = 0;
+    if (F64SRC) { d0 = a.offs[s]; D = a.offs[s + 1] - d0; }
+    else if (slot >= 0) D = a.counts32[slot];
+    int created = 0;
+    bool overflow = false;
+    for (int d = 0; d < D; ++d) {
+        double b0, b1, b2, b3, dconf;
+        int dcls;
+        if (F64SRC) {
+            const double *p = a.boxes64 + (size_t)(d0 + d) * 4;
+            b0 = p[0]; b1 = p[1]; b2 = p[2]; b3 = p[3];
+            dconf = a.conf64[d0 + d];
+            dcls = (int)a.cls64[d0 + d];
+        } else {
+            const size_t o = (size_t)slot * a.max_det + d;
+            const float4 f = a.boxes32[o];
+            b0 = (double)f.x; b1 = (double)f.y; b2 = (double)f.z; b3 = (double)f.w;  // exact widening
+            dconf = (double)a.scores32[o];
+            dcls = a.cls32[o];
+            if (!(dconf >= a.filter_thr)) continue;  // filter_detections, pipeline.py:182 (wave-uniform)
+        }
+        double best = 0.0;  // tracker.py:100
+        int bi = INT_MAX;
+        for (int k = lane; k < n; k += 64) {
+            if (l_cls[k] != dcls) continue;  // :103-104
+            const double v = iou64(l_box[k], l_box[cap + k], l_box[2 * cap + k], l_box[3 * cap + k], b0, b1, b2, b3);
+            if (v >= a.min_iou && v > best) { best = v; bi = k; }  // :106 (rows ascend within a lane)
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double ob = __shfl_xor(best, off);
+            const int oi = __shfl_xor(bi, off);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if (bi == INT_MAX) {  // :69-80 new track, appended immediately
+            if (n >= cap) { overflow = true; continue; }
+            if (lane == 0) {
+                l_box[n] = b0; l_box[cap + n] = b1; l_box[2 * cap + n] = b2; l_box[3 * cap + n] = b3;
+                l_conf[n] = dconf; l_id[n] = -(int64_t)(created + 1);
+                l_cls[n] = dcls; l_age[n] = 0; l_hits[n] = 1; l_match[n] = 1;
+            }
+            ++n; ++created;
+        } else if (lane == 0) {  // :81-92 (class_id is not updated)
+            l_box[bi] = b0; l_box[cap + bi] = b1; l_box[2 * cap + bi] = b2; l_box[3 * cap + bi] = b3;
+            l_conf[bi] = dconf; l_hits[bi] += 1; l_age[bi] = 0; l_match[bi] = 1;
+        }
+        __syncthreads();
+    }
+    // :111-126 prune, stable compaction back to HBM
+    int base = 0;
+    for (int k0 = 0; k0 < n; k0 += 64) {
+        const int k = k0 + lane;
+        bool keep = false;
+        int ag = 0;
+        if (k < n) {
+            ag = l_age[k];
+            if (l_match[k]) keep = true;
+            else { ag += 1; keep = !(ag > a.max_age || l_hits[k] < a.min_hits); }
+        }
+        const unsigned long long m = __ballot(keep);
+        if (keep) {
+            const size_t o = tb + base + __popcll(m & ((1ull << lane) - 1ull));
+            double *gb = a.box + o * 4;
+            gb[0] = l_box[k]; gb[1] = l_box[cap + k]; gb[2] = l_box[2 * cap + k]; gb[3] = l_box[3 * cap + k];
+            a.conf[o] = l_conf[k]; a.id[o] = l_id[k]; a.cls[o] = l_cls[k]; a.age[o] = ag; a.hits[o] = l_hits[k];
+        }
+        base += __popcll(m);
+    }
+    if (lane == 0) {
+        a.n_tracks[s] = base;
+        a.n_new[s] = created;
+        if (overflow) atomicOr(a.flags, 1);
+    }
+}
+
+// One block.  counts_all[n_global] in canonical order; local stream s sits at gidx[s].
+__global__ void __launch_bounds__(256) k4_assign_ids(int64_t *id, const int32_t *n_tracks, const int32_t *counts_all,
+                                                     int n_global, const int32_t *gidx, int n_streams, int cap,
+                                                     int64_t *next_id)
+{
+    __shared__ long long s_total;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    long long *prefix = (long long *)sm;  // [n_global] exclusive prefix
+    if (threadIdx.x == 0) {
+        long long acc = 0;
+        for (int g = 0; g < n_global; ++g) { prefix[g] = acc; acc += counts_all[g]; }
+        s_total = acc;
+    }
+    __syncthreads();
+    const long long first = *next_id;
+    for (int s = 0; s < n_streams; ++s) {
+        const long long b = first + prefix[gidx ? gidx[s] : s];
+        const int n = n_tracks[s];
+        for (int k = threadIdx.x; k < n; k += blockDim.x) {
+            const long long v = id[(size_t)s * cap + k];
+            if (v < 0) id[(size_t)s * cap + k] = b + (-v - 1);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *next_id = first + s_total;
+}
+
+size_t k4_smem_bytes(int cap) { return (size_t)cap * (4 * 8 + 8 + 8 + 4 * 4) + 64; }
+
+int launch_update(rva_tracker *t, K4Args &a, bool f64, hipStream_t stream)
+{
+    a.id = t->id; a.box = t->box; a.conf = t->conf; a.cls = t->cls; a.age = t->age; a.hits = t->hits;
+    a.n_tracks = t->n_tracks; a.n_new = t->n_new; a.flags = t->flags;
+    a.cap = t->cap; a.max_age = t->max_age; a.min_hits = t->min_hits; a.min_iou = t->min_iou;
+    const size_t smem = k4_smem_bytes(t->cap);
+    if (f64) k4_update<true><<<t->n_streams, 64, smem, stream>>>(a);
+    else k4_update<false><<<t->n_streams, 64, smem, stream>>>(a);
+    RVA_HIP(t->ctx, hipGetLastError());
+    return RVA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rva_tracker_create(rva_ctx *ctx, int n_streams, int capacity, int max_age, double max_iou_distance, int min_hits,
+                       rva_tracker **out)
+{
+    if (!ctx || !out || n_streams <= 0 || n_streams > RVA_MAX_TRACKER_STREAMS || capacity <= 0)
+        return rva_fail(ctx, RVA_ERR_ARG, "rva_tracker_create: bad argument (1 <= n_streams <= %d)", RVA_MAX_TRACKER_STREAMS);
+    const size_t smem = k4_smem_bytes(capacity);
+    if (smem > 160 * 1024) return rva_fail(ctx, RVA_ERR_CAPACITY, "tracker capacity %d needs %zu B of LDS (max 160 KiB)", capacity, smem);
+    RVA_HIP(ctx, hipSetDevice(ctx->device));
+    RVA_HIP(ctx, hipFuncSetAttribute((const void *)k4_update<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    RVA_HIP(ctx, hipFuncSetAttribute((const void *)k4_update<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    rva_tracker *t = new rva_tracker();
+    t->ctx = ctx; t->n_streams = n_streams; t->cap = capacity; t->max_age = max_age; t->min_hits = min_hits;
+    t->min_iou = max_iou_distance;
+    const size_t sc = (size_t)n_streams * capacity;
+    RVA_HIP(ctx, hipMalloc(&t->id, sc * 8));
+    RVA_HIP(ctx, hipMalloc(&t->box, sc * 32));
+    RVA_HIP(ctx, hipMalloc(&t->conf, sc * 8));
+    RVA_HIP(ctx, hipMalloc(&t->cls, sc * 4));
+    RVA_HIP(ctx, hipMalloc(&t->age, sc * 4));
+    RVA_HIP(ctx, hipMalloc(&t->hits, sc * 4));
+    RVA_HIP(ctx, hipMalloc(&t->n_tracks, n_streams * 4));
+    RVA_HIP(ctx, hipMalloc(&t->n_new, n_streams * 4));
+    RVA_HIP(ctx, hipMalloc(&t->next_id, 8));
+    RVA_HIP(ctx, hipMalloc(&t->flags, 4));
+    RVA_HIP(ctx, hipMalloc(&t->d_slot, n_streams * 4));
+    RVA_HIP(ctx, hipMalloc(&t->d_offs, (n_streams + 1) * 4));
+    RVA_HIP(ctx, hipMalloc(&t->d_gidx, n_streams * 4));
+    RVA_HIP(ctx, hipHostMalloc(&t->h_slot, n_streams * 4));
+    RVA_HIP(ctx, hipHostMalloc(&t->h_offs, (n_streams + 1) * 4));
+    RVA_HIP(ctx, hipEventCreateWithFlags(&t->staged, hipEventDisableTiming));
+    t->h_read_bytes = sc * (8 + 32 + 8 + 4 + 4 + 4) + n_streams * 4 + 64;
+    RVA_HIP(ctx, hipHostMalloc(&t->h_read, t->h_read_bytes));
+    RVA_HIP(ctx, hipMemset(t->n_tracks, 0, n_streams * 4));
+    RVA_HIP(ctx, hipMemset(t->n_new, 0, n_streams * 4));
+    RVA_HIP(ctx, hipMemset(t->flags, 0, 4));
+    const int64_t one = 1;  // itertools.count(1), tracker.py:47
+    RVA_HIP(ctx, hipMemcpy(t->next_id, &one, 8, hipMemcpyHostToDevice));
+    *out = t;
+    return RVA_OK;
+}
+
+void rva_tracker_destroy(rva_tracker *t)
+{
+    if (!t) return;
+    (void)hipSetDevice(t->ctx->device);
+    (void)hipDeviceSynchronize();
+    void *dev[] = {t->id, t->box, t->conf, t->cls, t->age, t->hits, t->n_tracks, t->n_new, t->next_id, t->flags,
+                   t->d_slot, t->d_offs, t->d_gidx};
+    for (void *p : dev) (void)hipFree(p);
+    void *host[] = {t->h_slot, t->h_offs, t->h_read};
+    for (void *p : host) (void)hipHostFree(p);
+    if (t->staged) (void)hipEventDestroy(t->staged);
+    delete t;
+}
+
+int rva_tracker_update_f32(rva_tracker *t, const int32_t *slot_of_stream, const float *boxes, const float *scores,
+                           const int32_t *cls, const int32_t *counts, int max_det, double filter_thr,
+                           rva_stream_t stream_)
+{
+    if (!t || !slot_of_stream) return RVA_ERR_ARG;
+    hipStream_t stream = (hipStream_t)stream_;
+    bool any = false;
+    K4Args a{};
+    for (int s = 0; s < t->n_streams; ++s) {
+        a.kslot[s] = slot_of_stream[s];
+        any |= slot_of_stream[s] >= 0;
+    }
+    if (any && (!boxes || !scores || !cls || !counts || max_det <= 0))
+        return rva_fail(t->ctx, RVA_ERR_ARG, "rva_tracker_update_f32: detection arrays missing");
+    a.boxes32 = (const float4 *)boxes; a.scores32 = scores; a.cls32 = cls; a.counts32 = counts; a.max_det = max_det;
+    a.filter_thr = filter_thr;
+    return launch_update(t, a, false, stream);
+}
+
+int rva_tracker_update_f64(rva_tracker *t, const int32_t *active, const int32_t *offsets, const double *boxes,
+                           const double *conf, const int64_t *cls, rva_stream_t stream_)
+{
+    if (!t || !active || !offsets) return RVA_ERR_ARG;
+    hipStream_t stream = (hipStream_t)stream_;
+    RVA_HIP(t->ctx, hipEventSynchronize(t->staged));  // previous tick's copies have left the staging buffers
+    for (int s = 0; s < t->n_streams; ++s) { t->h_slot[s] = active[s] ? 1 : 0; t->h_offs[s] = offsets[s]; }
+    t->h_offs[t->n_streams] = offsets[t->n_streams];
+    RVA_HIP(t->ctx, hipMemcpyAsync(t->d_slot, t->h_slot, t->n_streams * 4, hipMemcpyHostToDevice, stream));
+    RVA_HIP(t->ctx, hipMemcpyAsync(t->d_offs, t->h_offs, (t->n_streams + 1) * 4, hipMemcpyHostToDevice, stream));
+    RVA_HIP(t->ctx, hipEventRecord(t->staged, stream));
+    K4Args a{};
+    a.slot = t->d_slot; a.offs = t->d_offs; a.boxes64 = boxes; a.conf64 = conf; a.cls64 = cls;
+    return launch_update(t, a, true, stream);
+}
+
+int32_t *rva_tracker_new_counts(rva_tracker *t) { return t ? t->n_new : nullptr; }
+
+int rva_tracker_assign_ids(rva_tracker *t, const int32_t *counts_all, int n_global, const int32_t *global_index,
+                           rva_stream_t stream_)
+{
+    if (!t) return RVA_ERR_ARG;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int32_t *gidx = nullptr;
+    if (!counts_all) { counts_all = t->n_new; n_global = t->n_streams; global_index = nullptr; }
+    if (n_global <= 0 || n_global > 4096) return rva_fail(t->ctx, RVA_ERR_ARG, "n_global out of range");
+    if (global_index) {
+        bool same = (int)t->gidx_cached.size() == t->n_streams;
+        for (int s = 0; s < t->n_streams; ++s) {
+            if (global_index[s] < 0 || global_index[s] >= n_global) return rva_fail(t->ctx, RVA_ERR_ARG, "global_index out of range");
+            same = same && t->gidx_cached[s] == global_index[s];
+        }
+        if (!same) {  // the mapping is fixed for a job: uploaded once, synchronously
+            t->gidx_cached.assign(global_index, global_index + t->n_streams);
+            RVA_HIP(t->ctx, hipMemcpy(t->d_gidx, global_index, t->n_streams * 4, hipMemcpyHostToDevice));
+        }
+        gidx = t->d_gidx;
+    } else if (n_global != t->n_streams) {
+        return rva_fail(t->ctx, RVA_ERR_ARG, "global_index required when n_global != n_streams");
+    }
+    k4_assign_ids<<<1, 256, (size_t)n_global * 8, stream>>>(t->id, t->n_tracks, counts_all, n_global, gidx,
+                                                            t->n_streams, t->cap, t->next_id);
+    RVA_HIP(t->ctx, hipGetLastError());
+    return RVA_OK;
+}
+
+int rva_tracker_read_all(rva_tracker *t, int64_t *ids, int32_t *cls, int32_t *age, int32_t *hits, double *conf,
+                         double *boxes, int32_t *counts, rva_stream_t stream_)
+{
+    if (!t) return RVA_ERR_ARG;
+    hipStream_t stream = (hipStream_t)stream_;
+    const size_t sc = (size_t)t->n_streams * t->cap;
+    char *h = (char *)t->h_read;
+    size_t off = 0;
+    auto pull = [&](void *dst, const void *src, size_t bytes) -> hipError_t {
+        if (!dst) return hipSuccess;
+        hipError_t e = hipMemcpyAsync(h + off, src, bytes, hipMemcpyDeviceToHost, stream);
+        off += (bytes + 63) & ~(size_t)63;
+        return e;
+    };
+    size_t o_ids = off;    RVA_HIP(t->ctx, pull(ids, t->id, sc * 8));
+    size_t o_box = off;    RVA_HIP(t->ctx, pull(boxes, t->box, sc * 32));
+    size_t o_conf = off;   RVA_HIP(t->ctx, pull(conf, t->conf, sc * 8));
+    size_t o_cls = off;    RVA_HIP(t->ctx, pull(cls, t->cls, sc * 4));
+    size_t o_age = off;    RVA_HIP(t->ctx, pull(age, t->age, sc * 4));
+    size_t o_hits = off;   RVA_HIP(t->ctx, pull(hits, t->hits, sc * 4));
+    size_t o_cnt = off;    RVA_HIP(t->ctx, pull(counts, t->n_tracks, (size_t)t->n_streams * 4));
+    RVA_HIP(t->ctx, hipStreamSynchronize(stream));
+    if (ids) std::memcpy(ids, h + o_ids, sc * 8);
+    if (boxes) std::memcpy(boxes, h + o_box, sc * 32);
+    if (conf) std::memcpy(conf, h + o_conf, sc * 8);
+    if (cls) std::memcpy(cls, h + o_cls, sc * 4);
+    if (age) std::memcpy(age, h + o_age, sc * 4);
+    if (hits) std::memcpy(hits, h + o_hits, sc * 4);
+    if (counts) std::memcpy(counts, h + o_cnt, (size_t)t->n_streams * 4);
+    return RVA_OK;
+}
+
+int rva_tracker_read(rva_tracker *t, int stream_id, int cap, int64_t *ids, int32_t *cls, int32_t *age, int32_t *hits,
+                     double *conf, double *boxes, int32_t *n, rva_stream_t stream_)
+{
+    if (!t || stream_id < 0 || stream_id >= t->n_streams || !n || cap < 0) return RVA_ERR_ARG;
+    hipStream_t stream = (hipStream_t)stream_;
+    int32_t cnt = 0;
+    RVA_HIP(t->ctx, hipMemcpyAsync(&cnt, t->n_tracks + stream_id, 4, hipMemcpyDeviceToHost, stream));
+    RVA_HIP(t->ctx, hipStreamSynchronize(stream));
+    *n = cnt;
+    const int m = cnt < cap ? cnt : cap;
+    if (m <= 0) return RVA_OK;
+    const size_t tb = (size_t)stream_id * t->cap;
+    if (ids) RVA_HIP(t->ctx, hipMemcpyAsync(ids, t->id + tb, (size_t)m * 8, hipMemcpyDeviceToHost, stream));
+    if (boxes) RVA_HIP(t->ctx, hipMemcpyAsync(boxes, t->box + tb * 4, (size_t)m * 32, hipMemcpyDeviceToHost, stream));
+    if (conf) RVA_HIP(t->ctx, hipMemcpyAsync(conf, t->conf + tb, (size_t)m * 8, hipMemcpyDeviceToHost, stream));
+    if (cls) RVA_HIP(t->ctx, hipMemcpyAsync(cls, t->cls + tb, (size_t)m * 4, hipMemcpyDeviceToHost, stream));
+    if (age) RVA_HIP(t->ctx, hipMemcpyAsync(age, t->age + tb, (size_t)m * 4, hipMemcpyDeviceToHost, stream));
+    if (hits) RVA_HIP(t->ctx, hipMemcpyAsync(hits, t->hits + tb, (size_t)m * 4, hipMemcpyDeviceToHost, stream));
+    RVA_HIP(t->ctx, hipStreamSynchronize(stream));
+    return RVA_OK;
+}
+
+int rva_tracker_state(rva_tracker *t, int64_t *next_id, int *flags, rva_stream_t stream_)
+{
+    if (!t) return RVA_ERR_ARG;
+    hipStream_t stream = (hipStream_t)stream_;
+    int64_t nid = 0;
+    int32_t fl = 0;
+    RVA_HIP(t->ctx, hipMemcpyAsync(&nid, t->next_id, 8, hipMemcpyDeviceToHost, stream));
+    RVA_HIP(t->ctx, hipMemcpyAsync(&fl, t->flags, 4, hipMemcpyDeviceToHost, stream));
+    RVA_HIP(t->ctx, hipStreamSynchronize(stream));
+    if (next_id) *next_id = nid;
+    if (flags) *flags = fl;
+    return RVA_OK;
+}
+
+int rva_tracker_set_next_id(rva_tracker *t, int64_t next_id, rva_stream_t stream_)
+{
+    if (!t) return RVA_ERR_ARG;
+    hipStream_t stream = (hipStream_t)stream_;
+    RVA_HIP(t->ctx, hipMemcpyAsync(t->next_id, &next_id, 8, hipMemcpyHostToDevice, stream));
+    RVA_HIP(t->ctx, hipStreamSynchronize(stream));
+    return RVA_OK;
+}
+
+}  // extern "C"

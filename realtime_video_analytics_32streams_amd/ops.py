@@ -1,0 +1,314 @@
+"""Thin torch-facing wrappers over the C ABI: device buffers and streams come from torch,
+every computation happens in librva.so (HIP).  No operation here has a torch/CPU fallback."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _native as N
+
+
+def _stream_ptr() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _require_cuda(t: torch.Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live in HBM (got a {t.device} tensor): the HIP hot path has no CPU fallback")
+
+
+_CTX: dict = {}
+
+
+def context(device: Optional[int] = None) -> N.Context:
+    """Per-device singleton context."""
+    if not torch.cuda.is_available():
+        raise RuntimeError("no HIP device visible to torch: the MI355X hot path cannot run (no CPU fallback)")
+    dev = torch.cuda.current_device() if device is None else device
+    if dev not in _CTX:
+        _CTX[dev] = N.Context(dev)
+    return _CTX[dev]
+
+
+# ------------------------------------------------------------------------------------------ K1
+@dataclass
+class Nv12Surface:
+    """A decoded frame resident in HBM: pitch-linear Y plane + interleaved UV plane."""
+    y: torch.Tensor    # uint8 [h, pitch]
+    uv: torch.Tensor   # uint8 [h/2, pitch]
+    width: int
+    height: int
+
+    @property
+    def pitch(self) -> int:
+        return int(self.y.stride(0))
+
+    @property
+    def shape(self) -> Tuple[int, int, int]:  # what packet.frame.shape[:2] is used for
+        return (self.height, self.width, 3)
+
+    @staticmethod
+    def from_numpy(y: np.ndarray, uv: np.ndarray, width: int, height: int, device="cuda") -> "Nv12Surface":
+        return Nv12Surface(torch.from_numpy(np.ascontiguousarray(y)).to(device),
+                           torch.from_numpy(np.ascontiguousarray(uv)).to(device), width, height)
+
+
+def preprocess_nv12(surfaces: Sequence[Nv12Surface], dst_hw=(640, 640), half: bool = True,
+                    out: Optional[torch.Tensor] = None, clip: bool = False, ctx: Optional[N.Context] = None):
+    """K1 over a tick of NV12 surfaces -> ``out[n,3,H,W]`` (+ letterbox meta unless ``clip``)."""
+    ctx = ctx or context()
+    n = len(surfaces)
+    w, h = surfaces[0].width, surfaces[0].height
+    for s in surfaces:
+        _require_cuda(s.y, "NV12 surface")
+        if (s.width, s.height) != (w, h):
+            raise ValueError("all surfaces of one launch must share one geometry")
+    dt = torch.float16 if half else torch.float32
+    if out is None:
+        out = torch.empty((n, 3, dst_hw[0], dst_hw[1]), dtype=dt, device=surfaces[0].y.device)
+    _require_cuda(out, "output tensor")
+    assert out.is_contiguous() and out.dtype == dt and tuple(out.shape) == (n, 3, dst_hw[0], dst_hw[1])
+    L = N.lib()
+    meta = N.Letterbox()
+    for b0 in range(0, n, N.RVA_MAX_BATCH):
+        chunk = surfaces[b0:b0 + N.RVA_MAX_BATCH]
+        yp, _k1 = N.ptr_array([s.y.data_ptr() for s in chunk])
+        up, _k2 = N.ptr_array([s.uv.data_ptr() for s in chunk])
+        pp, _k3 = N.i32_array([s.pitch for s in chunk])
+        optr = C.c_void_p(out[b0].data_ptr())
+        if clip:
+            rc = L.rva_preprocess_clip_nv12_batch(ctx.handle, yp, up, pp, len(chunk), w, h, optr,
+                                                  N.RVA_F16 if half else N.RVA_F32, dst_hw[1], dst_hw[0], _stream_ptr())
+        else:
+            rc = L.rva_preprocess_nv12_batch(ctx.handle, yp, up, pp, len(chunk), w, h, optr,
+                                             N.RVA_F16 if half else N.RVA_F32, dst_hw[1], dst_hw[0], C.byref(meta),
+                                             _stream_ptr())
+        ctx.check(rc, "rva_preprocess_nv12_batch")
+    return (out, None) if clip else (out, meta)
+
+
+def preprocess_bgr(frames: Sequence[torch.Tensor], dst_hw=(640, 640), half: bool = True,
+                   out: Optional[torch.Tensor] = None, clip: bool = False, ctx: Optional[N.Context] = None):
+    """K1 over device copies of BGR uint8 [h,w,3] frames (the reference's FramePacket.frame)."""
+    ctx = ctx or context()
+    n = len(frames)
+    h, w = int(frames[0].shape[0]), int(frames[0].shape[1])
+    for f in frames:
+        _require_cuda(f, "BGR frame")
+        assert f.dtype == torch.uint8 and f.dim() == 3 and f.shape[2] == 3 and f.stride(2) == 1 and f.stride(1) == 3
+        if (int(f.shape[0]), int(f.shape[1])) != (h, w):
+            raise ValueError("all frames of one launch must share one geometry")
+    dt = torch.float16 if half else torch.float32
+    if out is None:
+        out = torch.empty((n, 3, dst_hw[0], dst_hw[1]), dtype=dt, device=frames[0].device)
+    assert out.is_contiguous() and out.dtype == dt
+    L = N.lib()
+    meta = N.Letterbox()
+    for b0 in range(0, n, N.RVA_MAX_BATCH):
+        chunk = frames[b0:b0 + N.RVA_MAX_BATCH]
+        fp, _k1 = N.ptr_array([f.data_ptr() for f in chunk])
+        rb, _k2 = N.i32_array([int(f.stride(0)) for f in chunk])
+        optr = C.c_void_p(out[b0].data_ptr())
+        if clip:
+            rc = L.rva_preprocess_clip_bgr_batch(ctx.handle, fp, rb, len(chunk), w, h, optr,
+                                                 N.RVA_F16 if half else N.RVA_F32, dst_hw[1], dst_hw[0], _stream_ptr())
+        else:
+            rc = L.rva_preprocess_bgr_batch(ctx.handle, fp, rb, len(chunk), w, h, optr,
+                                            N.RVA_F16 if half else N.RVA_F32, dst_hw[1], dst_hw[0], C.byref(meta),
+                                            _stream_ptr())
+        ctx.check(rc, "rva_preprocess_bgr_batch")
+    return (out, None) if clip else (out, meta)
+
+
+# ------------------------------------------------------------------------------------------ K2+K3
+@dataclass
+class PostBuffers:
+    """Device-resident result of the post-process for a batch (SoA, [B, max_det])."""
+    boxes: torch.Tensor    # float32 [B, max_det, 4]
+    scores: torch.Tensor   # float32 [B, max_det]
+    cls: torch.Tensor      # int32
+    anchor: torch.Tensor   # int32
+    cand: torch.Tensor     # int32
+    counts: torch.Tensor   # int32 [B]
+    ncand: torch.Tensor    # int32 [B]
+    max_det: int
+
+    @staticmethod
+    def allocate(batch: int, max_det: int, device) -> "PostBuffers":
+        i32 = dict(dtype=torch.int32, device=device)
+        return PostBuffers(torch.empty((batch, max_det, 4), dtype=torch.float32, device=device),
+                           torch.empty((batch, max_det), dtype=torch.float32, device=device),
+                           torch.empty((batch, max_det), **i32), torch.empty((batch, max_det), **i32),
+                           torch.empty((batch, max_det), **i32), torch.zeros((batch,), **i32),
+                           torch.zeros((batch,), **i32), max_det)
+
+    def to_host(self) -> List[dict]:
+        """One D2H sync; per-image dicts in NMS order."""
+        counts = self.counts.cpu().numpy()
+        m = int(counts.max()) if len(counts) else 0
+        boxes = self.boxes[:, :m].cpu().numpy(); scores = self.scores[:, :m].cpu().numpy()
+        cls = self.cls[:, :m].cpu().numpy(); anchor = self.anchor[:, :m].cpu().numpy()
+        cand = self.cand[:, :m].cpu().numpy(); ncand = self.ncand.cpu().numpy()
+        return [dict(n=int(c), boxes=boxes[b, :c], conf=scores[b, :c], cls=cls[b, :c], anchor=anchor[b, :c],
+                     keep=cand[b, :c], n_cand=int(ncand[b])) for b, c in enumerate(counts)]
+
+
+def postprocess(raw: torch.Tensor, conf_thr: float, iou_thr: float, classes: Optional[Sequence[int]],
+                metas: Sequence[N.Letterbox], max_det: Optional[int] = None, out: Optional[PostBuffers] = None,
+                ctx: Optional[N.Context] = None) -> PostBuffers:
+    """K2+K3 over ``raw[B, d1, d2]`` (float16/float32, device)."""
+    ctx = ctx or context()
+    _require_cuda(raw, "head tensor")
+    if raw.dim() == 2:
+        raw = raw.unsqueeze(0)
+    assert raw.dim() == 3 and raw.is_contiguous() and raw.dtype in (torch.float16, torch.float32)
+    B, d1, d2 = (int(v) for v in raw.shape)
+    A = d2 if d1 < d2 else d1
+    max_det = max_det or A
+    if out is None:
+        out = PostBuffers.allocate(B, max_det, raw.device)
+    assert out.max_det == max_det and out.counts.shape[0] >= B
+    marr = (N.Letterbox * len(metas))(*metas)
+    cls_p, _keep = (N.i32_array(list(classes)) if classes else (None, None))
+    rc = N.lib().rva_postprocess_batch(
+        ctx.handle, C.c_void_p(raw.data_ptr()), N.RVA_F16 if raw.dtype == torch.float16 else N.RVA_F32, B, d1, d2,
+        float(conf_thr), float(iou_thr), cls_p, len(classes) if classes else 0, marr, len(metas), max_det,
+        C.c_void_p(out.boxes.data_ptr()), C.c_void_p(out.scores.data_ptr()), C.c_void_p(out.cls.data_ptr()),
+        C.c_void_p(out.anchor.data_ptr()), C.c_void_p(out.cand.data_ptr()), C.c_void_p(out.counts.data_ptr()),
+        C.c_void_p(out.ncand.data_ptr()), _stream_ptr())
+    ctx.check(rc, "rva_postprocess_batch")
+    return out
+
+
+def post_status(ctx: Optional[N.Context] = None) -> int:
+    ctx = ctx or context()
+    f = C.c_int()
+    ctx.check(N.lib().rva_post_status(ctx.handle, _stream_ptr(), C.byref(f)), "rva_post_status")
+    return f.value
+
+
+# ------------------------------------------------------------------------------------------ K4
+class DeviceTracker:
+    """All per-stream track tables of this process, resident in HBM (wraps ``rva_tracker``)."""
+
+    def __init__(self, n_streams: int, max_age: int = 30, max_iou_distance: float = 0.7, min_hits: int = 3,
+                 capacity: int = 1024, ctx: Optional[N.Context] = None):
+        self.ctx = ctx or context()
+        self.n_streams, self.capacity = n_streams, capacity
+        h = C.c_void_p()
+        self.ctx.check(N.lib().rva_tracker_create(self.ctx.handle, n_streams, capacity, int(max_age),
+                                                  float(max_iou_distance), int(min_hits), C.byref(h)),
+                       "rva_tracker_create")
+        self.handle = h
+        self._new_counts_ptr = N.lib().rva_tracker_new_counts(h)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            N.lib().rva_tracker_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def update_from_post(self, slot_of_stream: Sequence[int], post: Optional[PostBuffers], filter_thr: float):
+        sp, _k = N.i32_array(list(slot_of_stream))
+        nul = C.c_void_p(None)
+        if post is None:
+            rc = N.lib().rva_tracker_update_f32(self.handle, sp, nul, nul, nul, nul, 0, float(filter_thr), _stream_ptr())
+        else:
+            rc = N.lib().rva_tracker_update_f32(self.handle, sp, C.c_void_p(post.boxes.data_ptr()),
+                                                C.c_void_p(post.scores.data_ptr()), C.c_void_p(post.cls.data_ptr()),
+                                                C.c_void_p(post.counts.data_ptr()), post.max_det, float(filter_thr),
+                                                _stream_ptr())
+        self.ctx.check(rc, "rva_tracker_update_f32")
+
+    def update_from_host(self, per_stream: dict):
+        """``per_stream[s] = (boxes f64 [D,4], conf f64 [D], cls i64 [D])`` for the streams to update."""
+        active = [0] * self.n_streams
+        offs = [0] * (self.n_streams + 1)
+        bl, cl, kl = [], [], []
+        tot = 0
+        for s in range(self.n_streams):
+            offs[s] = tot
+            if s in per_stream:
+                b, c, k = per_stream[s]
+                b = np.ascontiguousarray(b, np.float64).reshape(-1, 4)
+                active[s] = 1
+                bl.append(b); cl.append(np.ascontiguousarray(c, np.float64)); kl.append(np.ascontiguousarray(k, np.int64))
+                tot += len(b)
+        offs[self.n_streams] = tot
+        dev = torch.device("cuda", self.ctx.device)
+        if tot:
+            db = torch.from_numpy(np.concatenate(bl)).to(dev)
+            dc = torch.from_numpy(np.concatenate(cl)).to(dev)
+            dk = torch.from_numpy(np.concatenate(kl)).to(dev)
+        else:
+            db = torch.zeros((1, 4), dtype=torch.float64, device=dev)
+            dc = torch.zeros((1,), dtype=torch.float64, device=dev)
+            dk = torch.zeros((1,), dtype=torch.int64, device=dev)
+        ap, _k1 = N.i32_array(active)
+        op, _k2 = N.i32_array(offs)
+        rc = N.lib().rva_tracker_update_f64(self.handle, ap, op, C.c_void_p(db.data_ptr()), C.c_void_p(dc.data_ptr()),
+                                            C.c_void_p(dk.data_ptr()), _stream_ptr())
+        self.ctx.check(rc, "rva_tracker_update_f64")
+        self._keepalive = (db, dc, dk)
+
+    def new_counts_tensor(self) -> torch.Tensor:
+        """Zero-copy int32[n_streams] view of the device new-track counts of the last update."""
+        # built through the array interface so torch wraps, not copies, the librva-owned buffer
+        class _Holder:
+            pass
+        hld = _Holder()
+        hld.__cuda_array_interface__ = {"shape": (self.n_streams,), "typestr": "<i4",
+                                        "data": (int(self._new_counts_ptr), False), "version": 3}
+        return torch.as_tensor(hld, device=torch.device("cuda", self.ctx.device))
+
+    def assign_ids(self, counts_all: Optional[torch.Tensor] = None, global_index: Optional[Sequence[int]] = None):
+        if counts_all is None:
+            rc = N.lib().rva_tracker_assign_ids(self.handle, C.c_void_p(None), 0, None, _stream_ptr())
+        else:
+            assert counts_all.is_cuda and counts_all.dtype == torch.int32 and counts_all.is_contiguous()
+            gp, _k = N.i32_array(list(global_index)) if global_index is not None else (None, None)
+            rc = N.lib().rva_tracker_assign_ids(self.handle, C.c_void_p(counts_all.data_ptr()), int(counts_all.numel()),
+                                                gp, _stream_ptr())
+        self.ctx.check(rc, "rva_tracker_assign_ids")
+
+    def read(self, stream_id: int) -> dict:
+        cap = self.capacity
+        ids = np.empty(cap, np.int64); cls = np.empty(cap, np.int32); age = np.empty(cap, np.int32)
+        hits = np.empty(cap, np.int32); conf = np.empty(cap, np.float64); box = np.empty((cap, 4), np.float64)
+        n = C.c_int32()
+        rc = N.lib().rva_tracker_read(self.handle, stream_id, cap, C.c_void_p(ids.ctypes.data), C.c_void_p(cls.ctypes.data),
+                                      C.c_void_p(age.ctypes.data), C.c_void_p(hits.ctypes.data),
+                                      C.c_void_p(conf.ctypes.data), C.c_void_p(box.ctypes.data), C.byref(n), _stream_ptr())
+        self.ctx.check(rc, "rva_tracker_read")
+        m = n.value
+        return dict(n=m, id=ids[:m], cls=cls[:m], age=age[:m], hits=hits[:m], conf=conf[:m], boxes=box[:m])
+
+    def read_all(self) -> List[dict]:
+        S, cap = self.n_streams, self.capacity
+        ids = np.empty((S, cap), np.int64); cls = np.empty((S, cap), np.int32); age = np.empty((S, cap), np.int32)
+        hits = np.empty((S, cap), np.int32); conf = np.empty((S, cap), np.float64); box = np.empty((S, cap, 4), np.float64)
+        cnt = np.empty(S, np.int32)
+        rc = N.lib().rva_tracker_read_all(self.handle, C.c_void_p(ids.ctypes.data), C.c_void_p(cls.ctypes.data),
+                                          C.c_void_p(age.ctypes.data), C.c_void_p(hits.ctypes.data),
+                                          C.c_void_p(conf.ctypes.data), C.c_void_p(box.ctypes.data),
+                                          C.c_void_p(cnt.ctypes.data), _stream_ptr())
+        self.ctx.check(rc, "rva_tracker_read_all")
+        return [dict(n=int(cnt[s]), id=ids[s, :cnt[s]], cls=cls[s, :cnt[s]], age=age[s, :cnt[s]], hits=hits[s, :cnt[s]],
+                     conf=conf[s, :cnt[s]], boxes=box[s, :cnt[s]]) for s in range(S)]
+
+    def state(self) -> Tuple[int, int]:
+        nid = C.c_int64(); fl = C.c_int()
+        self.ctx.check(N.lib().rva_tracker_state(self.handle, C.byref(nid), C.byref(fl), _stream_ptr()), "rva_tracker_state")
+        return nid.value, fl.value
+
+    def set_next_id(self, v: int):
+        self.ctx.check(N.lib().rva_tracker_set_next_id(self.handle, int(v), _stream_ptr()), "rva_tracker_set_next_id")

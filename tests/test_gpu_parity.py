@@ -1,0 +1,335 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the committed goldens recorded
+from the reference, and against the CPU oracle on seeded inputs.  Need a real MI355X.
+
+Bars (BASELINE.json north_star): bit-exact track ids / kept-box indices; coords and scores within
+1e-3 -- these kernels are in fact held to exact float equality, the tolerance is never used.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+from realtime_video_analytics_32streams_amd import _native as N
+from realtime_video_analytics_32streams_amd import ops, synth
+from tests.conftest import load_golden
+from tests.helpers import head_for_case, script_sha, table_digest
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _post_one(raw2d, conf, iou, classes, wh, dtype=torch.float32):
+    t = torch.from_numpy(np.ascontiguousarray(raw2d)).to(DEV).to(dtype)[None].contiguous()
+    m = N.letterbox(wh[0], wh[1], 640, 640)
+    return ops.postprocess(t, conf, iou, classes, [m]).to_host()[0]
+
+
+def _case_id(c):
+    return f"{c['kind']}-{c.get('seed', c.get('name'))}-{c.get('model_type', 'v8')}"
+
+
+# ---------------------------------------------------------------------------------------- K2+K3
+@pytest.mark.parametrize("case", load_golden("post_cases.json")["cases"], ids=_case_id)
+def test_postprocess_matches_reference_goldens(case):
+    raw = head_for_case(case)
+    exp = case["expect"]
+    got = _post_one(raw, case["conf"], case["iou"], case["classes"], tuple(case["orig_wh"]))
+    assert got["n"] == exp["n"] and got["n_cand"] == exp["n_cand"]
+    assert got["anchor"].tolist() == exp["anchor"]
+    assert got["keep"].tolist() == exp["keep"]
+    assert got["cls"].tolist() == exp["cls"]
+    assert [float(v) for v in got["conf"]] == exp["conf"]
+    assert [[float(v) for v in b] for b in got["boxes"]] == exp["boxes"]
+
+
+def test_postprocess_batch32_matches_oracle_fp32_and_fp16():
+    """BASELINE config 3 shape: [32, 84, 8400]; every image checked against the oracle."""
+    seeds = list(range(100, 132))
+    heads = synth.make_head_batch(seeds, layout="CA", n_obj=30)
+    metas = [N.letterbox(1920, 1080, 640, 640)]
+    for dtype in (torch.float32, torch.float16):
+        t = torch.from_numpy(heads).to(DEV).to(dtype).contiguous()
+        res = ops.postprocess(t, 0.25, 0.45, None, metas).to_host()
+        ref_in = t.float().cpu().numpy()          # the oracle sees exactly the values the kernel saw
+        for b in range(len(seeds)):
+            want = orc.postprocess(ref_in[b], 0.25, 0.45, None, (1920, 1080))
+            got = res[b]
+            assert got["n"] == want["n"] and got["n_cand"] == want["n_cand"], (dtype, b)
+            if dtype == torch.float16:
+                # fp16 heads make score ties likely; the project tie rule is (score desc, anchor asc)
+                assert len(np.unique(want["conf"])) <= want["n"]
+            assert np.array_equal(got["anchor"], want["anchor"]), (dtype, b)
+            assert np.array_equal(got["keep"], want["keep"])
+            assert np.array_equal(got["cls"], want["cls"])
+            assert np.array_equal(got["conf"], want["conf"])
+            assert np.array_equal(got["boxes"], want["boxes"])
+    assert ops.post_status() == 0
+
+
+def test_postprocess_score_ties_follow_project_rule():
+    head = synth.make_head(77, n_obj=10)
+    head[:, 4:] = np.round(head[:, 4:] * 16) / 16        # quantise -> many exact score ties
+    raw = np.ascontiguousarray(head.T)
+    got = _post_one(raw, 0.25, 0.45, None, (1920, 1080))
+    want = orc.postprocess(raw, 0.25, 0.45, None, (1920, 1080))
+    assert want["n"] > 3 and len(np.unique(want["conf"])) < want["n_cand"]
+    assert np.array_equal(got["anchor"], want["anchor"]) and np.array_equal(got["boxes"], want["boxes"])
+
+
+def test_postprocess_worst_case_every_anchor_is_a_candidate():
+    """K = 8400 candidates (maximum size): sort + chunked NMS must still equal the sequential loop."""
+    rng = np.random.default_rng(5)
+    A = 8400
+    p = np.empty((A, 84), np.float32)
+    p[:, 0] = rng.uniform(0, 640, A); p[:, 1] = rng.uniform(140, 500, A)
+    p[:, 2] = rng.uniform(20, 120, A); p[:, 3] = rng.uniform(20, 120, A)
+    p[:, 4] = rng.uniform(0.9, 1.0, A)
+    p[:, 5:] = rng.uniform(0.3, 1.0, (A, 79))
+    raw = np.ascontiguousarray(p.T)
+    got = _post_one(raw, 0.25, 0.5, None, (1920, 1080))
+    want = orc.postprocess(raw, 0.25, 0.5, None, (1920, 1080))
+    assert want["n_cand"] == A and got["n_cand"] == A
+    assert got["n"] == want["n"] and np.array_equal(got["anchor"], want["anchor"])
+    assert np.array_equal(got["boxes"], want["boxes"]) and np.array_equal(got["conf"], want["conf"])
+
+
+def test_postprocess_properties_at_full_size():
+    """Size-independent properties on the [32,84,8400] workload: idempotence of NMS on its own
+    output, descending scores, every kept pair has IoU <= thr."""
+    heads = synth.make_head_batch(list(range(200, 232)), layout="CA", n_obj=60)
+    t = torch.from_numpy(heads).to(DEV)
+    res = ops.postprocess(t, 0.2, 0.5, None, [N.letterbox(1920, 1080, 640, 640)]).to_host()
+    for r in res:
+        assert r["n"] > 0 and np.all(np.diff(r["conf"]) <= 0)
+        b = r["boxes"].astype(np.float32)
+        x1 = np.maximum(b[:, None, 0], b[None, :, 0]); y1 = np.maximum(b[:, None, 1], b[None, :, 1])
+        x2 = np.minimum(b[:, None, 2], b[None, :, 2]); y2 = np.minimum(b[:, None, 3], b[None, :, 3])
+        inter = np.maximum(0, x2 - x1) * np.maximum(0, y2 - y1)
+        area = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+        iou = inter / np.clip(area[:, None] + area[None, :] - inter, 1e-6, None)
+        np.fill_diagonal(iou, 0)
+        assert np.all(iou <= np.float32(0.5))
+        assert np.all(b[:, [0, 2]] >= 0) and np.all(b[:, [0, 2]] <= 1919) and np.all(b[:, [1, 3]] <= 1079)
+
+
+def test_postprocess_bad_shape_and_empty():
+    t = torch.zeros((2, 10, 4), device=DEV)
+    res = ops.postprocess(t, 0.25, 0.45, None, [N.letterbox(1920, 1080, 640, 640)]).to_host()
+    assert [r["n"] for r in res] == [0, 0]
+    t = torch.zeros((3, 84, 8400), device=DEV)
+    res = ops.postprocess(t, 0.25, 0.45, None, [N.letterbox(1920, 1080, 640, 640)]).to_host()
+    assert [r["n"] for r in res] == [0, 0, 0]
+
+
+# ---------------------------------------------------------------------------------------- K4
+def _gpu_table(res):
+    return orc.table_of(res)
+
+
+def test_tracker_inline_probes_match_reference(tracker_cases):
+    for probe in tracker_cases["inline"]:
+        cfg = probe["cfg"]
+        names = sorted({s["stream"] for s in probe["steps"]})
+        trk = ops.DeviceTracker(len(names), cfg["max_age"], cfg["max_iou_distance"], cfg["min_hits"], capacity=64)
+        for step in probe["steps"]:
+            s = names.index(step["stream"])
+            trk.update_from_host({s: (np.asarray(step["boxes"], np.float64).reshape(-1, 4), step["conf"], step["cls"])})
+            trk.assign_ids()
+            assert _gpu_table(trk.read(s)) == step["table"], probe["name"]
+        trk.close()
+
+
+@pytest.mark.parametrize("idx", range(5))
+def test_tracker_seeded_scripts_match_reference(tracker_cases, idx):
+    """Streams are updated one at a time in canonical order, exactly as the golden harness drove
+    the reference tracker; per-update digests of the full table must match."""
+    case = tracker_cases["seeded"][idx]
+    cfg = case["cfg"]
+    script = synth.make_tracker_script(case["seed"], case["n_streams"], case["n_ticks"], n_obj=case["n_obj"])
+    assert script_sha(script) == case["sha"]
+    trk = ops.DeviceTracker(case["n_streams"], cfg["max_age"], cfg["max_iou_distance"], cfg["min_hits"], capacity=1024)
+    k = 0
+    for t in range(case["n_ticks"]):
+        for s in range(case["n_streams"]):
+            fd = script[t][s]
+            m = fd.conf >= case["conf_thr"]
+            trk.update_from_host({s: (fd.boxes[m], fd.conf[m], fd.cls[m])})
+            trk.assign_ids()
+            assert table_digest(_gpu_table(trk.read(s))) == case["digests"][k], (t, s)
+            k += 1
+    final = {f"s{s}": _gpu_table(trk.read(s)) for s in range(case["n_streams"])}
+    assert final == case["final"]
+    assert trk.state()[1] == 0
+    trk.close()
+
+
+@pytest.mark.parametrize("idx", [0, 2, 3])
+def test_tracker_batched_tick_equals_sequential_reference(tracker_cases, idx):
+    """All streams of a tick updated CONCURRENTLY (one wavefront each) + one id-assignment pass
+    must reproduce the ids the reference hands out when called stream after stream."""
+    case = tracker_cases["seeded"][idx]
+    cfg = case["cfg"]
+    S = case["n_streams"]
+    script = synth.make_tracker_script(case["seed"], S, case["n_ticks"], n_obj=case["n_obj"])
+    trk = ops.DeviceTracker(S, cfg["max_age"], cfg["max_iou_distance"], cfg["min_hits"], capacity=1024)
+    k = 0
+    for t in range(case["n_ticks"]):
+        upd = {}
+        for s in range(S):
+            fd = script[t][s]
+            m = fd.conf >= case["conf_thr"]
+            upd[s] = (fd.boxes[m], fd.conf[m], fd.cls[m])
+        trk.update_from_host(upd)
+        trk.assign_ids()
+        tabs = trk.read_all()
+        for s in range(S):
+            assert table_digest(_gpu_table(tabs[s])) == case["digests"][k], (t, s)
+            k += 1
+    trk.close()
+
+
+def test_tracker_fused_f32_path_with_filter_and_skips():
+    """Device-resident detections (the post-process output layout) + F1 filter inside the kernel,
+    idle (-1) and skipped-frame (-2) slots; oracle driven in canonical order."""
+    S, T, max_det = 6, 25, 64
+    script = synth.make_tracker_script(21, S, T, n_obj=10)
+    thr = 0.45
+    trk = ops.DeviceTracker(S, 4, 0.4, 2, capacity=256)
+    ref = orc.Tracker(S, 4, 0.4, 2)
+    rng = np.random.default_rng(3)
+    for t in range(T):
+        post = ops.PostBuffers.allocate(S, max_det, DEV)
+        slots, boxes, scores, cls, counts = [], np.zeros((S, max_det, 4), np.float32), np.zeros((S, max_det), np.float32), \
+            np.zeros((S, max_det), np.int32), np.zeros(S, np.int32)
+        row = 0
+        want = {}
+        for s in range(S):
+            mode = rng.random()
+            fd = script[t][s]
+            if mode < 0.1:
+                slots.append(-1)                 # no frame this tick: table untouched
+                continue
+            if mode < 0.2:
+                slots.append(-2)                 # skipped frame: update(name, [])
+                want[s] = ref.update(s, np.zeros((0, 4)), [], [])
+                continue
+            d = len(fd.conf)
+            boxes[row, :d] = fd.boxes; scores[row, :d] = fd.conf; cls[row, :d] = fd.cls; counts[row] = d
+            slots.append(row)
+            m = fd.conf >= thr
+            want[s] = ref.update(s, fd.boxes[m], fd.conf[m], fd.cls[m])
+            row += 1
+        post.boxes.copy_(torch.from_numpy(boxes)); post.scores.copy_(torch.from_numpy(scores))
+        post.cls.copy_(torch.from_numpy(cls)); post.counts.copy_(torch.from_numpy(counts))
+        trk.update_from_post(slots, post, thr)
+        trk.assign_ids()
+        tabs = trk.read_all()
+        for s, w in want.items():
+            assert _gpu_table(tabs[s]) == orc.table_of(w), (t, s)
+    assert trk.state()[0] == ref.next_id
+    trk.close()
+
+
+def test_tracker_sharded_ids_match_single_process():
+    """Two trackers owning interleaved halves of 8 streams + exchanged new-track counts reproduce the
+    ids of one tracker owning all 8 (the multi-GPU scheme of SURVEY.md 8e, on one device)."""
+    S, T = 8, 20
+    script = synth.make_tracker_script(31, S, T, n_obj=6)
+    full = ops.DeviceTracker(S, 10, 0.5, 1, capacity=256)
+    own = [[0, 2, 4, 6], [1, 3, 5, 7]]
+    parts = [ops.DeviceTracker(4, 10, 0.5, 1, capacity=256) for _ in own]
+    for t in range(T):
+        full.update_from_host({s: (script[t][s].boxes, script[t][s].conf, script[t][s].cls) for s in range(S)})
+        full.assign_ids()
+        counts_all = torch.zeros(S, dtype=torch.int32, device=DEV)
+        for p, streams in zip(parts, own):
+            p.update_from_host({i: (script[t][s].boxes, script[t][s].conf, script[t][s].cls) for i, s in enumerate(streams)})
+            counts_all[torch.tensor(streams, device=DEV)] = p.new_counts_tensor()
+        for p, streams in zip(parts, own):
+            p.assign_ids(counts_all, streams)
+        ftab = full.read_all()
+        for p, streams in zip(parts, own):
+            ptab = p.read_all()
+            for i, s in enumerate(streams):
+                assert _gpu_table(ptab[i]) == _gpu_table(ftab[s]), (t, s)
+    assert parts[0].state()[0] == full.state()[0] == parts[1].state()[0]
+
+
+def test_tracker_capacity_overflow_is_flagged():
+    trk = ops.DeviceTracker(1, 30, 0.5, 1, capacity=8)
+    boxes = np.array([[i * 50.0, 0, i * 50.0 + 20, 20] for i in range(12)])
+    trk.update_from_host({0: (boxes, np.full(12, 0.9), np.zeros(12, np.int64))})
+    trk.assign_ids()
+    assert trk.read(0)["n"] == 8 and trk.state()[1] & 1
+
+
+# ---------------------------------------------------------------------------------------- K1
+GEOMS = [(1920, 1080), (3840, 2160), (1280, 720), (640, 360), (2560, 1440), (1000, 700), (722, 1282), (96, 54)]
+
+
+@pytest.mark.parametrize("wh", GEOMS, ids=lambda g: f"{g[0]}x{g[1]}")
+@pytest.mark.parametrize("half", [True, False], ids=["fp16", "fp32"])
+def test_preprocess_nv12_bit_exact(wh, half):
+    w, h = wh
+    pitch = ((w + 255) // 256) * 256
+    frames = [synth.make_nv12(synth.SEED_BASE + 1000 * s, w, h, pitch, tick=s) for s in range(2)]
+    surfs = [ops.Nv12Surface.from_numpy(y, uv, w, h) for y, uv in frames]
+    out, meta = ops.preprocess_nv12(surfs, (640, 640), half=half)
+    got = out.cpu().numpy()
+    for i, (y, uv) in enumerate(frames):
+        want, m = orc.preprocess_nv12(y, uv, w, h, 640, 640, half)
+        assert meta.as_meta() == m
+        view = np.uint16 if half else np.uint32
+        assert np.array_equal(got[i].view(view), want.view(view)), (wh, half, i)
+
+
+@pytest.mark.parametrize("wh", [(1920, 1080), (1001, 701), (333, 777), (640, 640), (64, 48)], ids=lambda g: f"{g[0]}x{g[1]}")
+def test_preprocess_bgr_bit_exact(wh):
+    w, h = wh
+    frames = [synth.make_bgr(9 + i, w, h) for i in range(2)]
+    dev = [torch.from_numpy(f).to(DEV) for f in frames]
+    for half in (True, False):
+        out, meta = ops.preprocess_bgr(dev, (640, 640), half=half)
+        got = out.cpu().numpy()
+        for i, f in enumerate(frames):
+            want, m = orc.preprocess_bgr(f, 640, 640, half)
+            assert meta.as_meta() == m
+            view = np.uint16 if half else np.uint32
+            assert np.array_equal(got[i].view(view), want.view(view))
+
+
+def test_preprocess_other_input_sizes():
+    for dst in [(416, 416), (320, 416), (1280, 1280)]:
+        y, uv = synth.make_nv12(5, 1920, 1080)
+        out, meta = ops.preprocess_nv12([ops.Nv12Surface.from_numpy(y, uv, 1920, 1080)], dst, half=True)
+        want, m = orc.preprocess_nv12(y, uv, 1920, 1080, dst[1], dst[0], True)
+        assert meta.as_meta() == m and np.array_equal(out.cpu().numpy()[0].view(np.uint16), want.view(np.uint16))
+
+
+def test_preprocess_full_tick_32x1080p_properties():
+    """BASELINE config 3 size (32 x 1080p): pad rows are 114/255, content equals the decimated
+    colour-converted source (size-independent property), identical surfaces give identical planes."""
+    y, uv = synth.make_nv12(1, 1920, 1080, 2048)
+    s0 = ops.Nv12Surface.from_numpy(y, uv, 1920, 1080)
+    surfs = [s0] * 31 + [ops.Nv12Surface.from_numpy(*synth.make_nv12(2, 1920, 1080, 2048), 1920, 1080)]
+    out, meta = ops.preprocess_nv12(surfs, (640, 640), half=True)
+    pad = (np.float16(114) * np.float16(1 / 255)).view(np.uint16)
+    o = out.cpu().numpy().view(np.uint16)
+    assert np.all(o[:, :, :140] == pad) and np.all(o[:, :, 500:] == pad)
+    assert all(np.array_equal(o[0], o[i]) for i in range(1, 31)) and not np.array_equal(o[0], o[31])
+    bgr = orc.nv12_to_bgr(y, uv, 1920, 1080)[1::3, 1::3]
+    want = (bgr[..., ::-1].astype(np.float16) * np.float16(1 / 255)).transpose(2, 0, 1)
+    assert np.array_equal(o[0][:, 140:500], want.view(np.uint16))
+
+
+@pytest.mark.parametrize("half", [False, True], ids=["fp32", "fp16"])
+def test_preprocess_clip_frames(half):
+    y, uv = synth.make_nv12(8, 3840, 2160)
+    out, _ = ops.preprocess_nv12([ops.Nv12Surface.from_numpy(y, uv, 3840, 2160)], (224, 224), half=half, clip=True)
+    want = orc.preprocess_clip_frame(nv12=(y, uv), wh=(3840, 2160), tw=224, th=224, half=half)
+    view = np.uint16 if half else np.uint32
+    assert np.array_equal(out.cpu().numpy()[0].view(view), want.view(view))
+    f = synth.make_bgr(4, 500, 300)
+    out, _ = ops.preprocess_bgr([torch.from_numpy(f).to(DEV)], (112, 112), half=half, clip=True)
+    want = orc.preprocess_clip_frame(bgr=f, tw=112, th=112, half=half)
+    assert np.array_equal(out.cpu().numpy()[0].view(view), want.view(view))
