@@ -164,14 +164,19 @@ int rva_tracker_assign_ids(rva_tracker *trk, const int32_t *counts_all, int n_gl
                            const int32_t *global_index, rva_stream_t stream);
 
 /* Host-synchronous read-back of one stream's table in insertion order (Track fields of
- * tracker.py:18-27).  Returns the row count in *n (rows beyond `cap` are not copied). */
+ * tracker.py:18-27).  Returns the row count in *n (rows beyond `cap` are not copied).
+ * last_det[i] = index (within the stream's detection list of the latest update) of the last
+ * detection that created/overwrote row i, or -1: lets the host carry the optional temporal
+ * fields of tracker.py:58-67,88-90 without shipping strings to the device.  May be NULL. */
 int rva_tracker_read(rva_tracker *trk, int stream_id, int cap, int64_t *ids, int32_t *cls, int32_t *age,
-                     int32_t *hits, double *conf, double *boxes, int32_t *n, rva_stream_t stream);
+                     int32_t *hits, double *conf, double *boxes, int32_t *last_det, int32_t *n,
+                     rva_stream_t stream);
 
 /* Host-synchronous read-back of every stream at once: arrays are [n_streams, capacity(,4)],
  * counts[n_streams]; any pointer may be NULL. */
 int rva_tracker_read_all(rva_tracker *trk, int64_t *ids, int32_t *cls, int32_t *age, int32_t *hits,
-                         double *conf, double *boxes, int32_t *counts, rva_stream_t stream);
+                         double *conf, double *boxes, int32_t *last_det, int32_t *counts,
+                         rva_stream_t stream);
 
 /* Host-synchronous: next id the counter will hand out; flags bit 0 = a table overflowed `capacity`. */
 int rva_tracker_state(rva_tracker *trk, int64_t *next_id, int *flags, rva_stream_t stream);

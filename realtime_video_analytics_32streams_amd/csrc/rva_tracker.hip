@@ -31,6 +31,7 @@ struct rva_tracker {
     int32_t *cls = nullptr;    // [S][cap]
     int32_t *age = nullptr;    // [S][cap]
     int32_t *hits = nullptr;   // [S][cap]
+    int32_t *last_det = nullptr;  // [S][cap] index of the last detection of the latest update that wrote the row, -1 if none
     int32_t *n_tracks = nullptr;  // [S]
     int32_t *n_new = nullptr;     // [S]
     int64_t *next_id = nullptr;   // [1]
@@ -49,7 +50,7 @@ struct rva_tracker {
 namespace {
 
 struct K4Args {
-    int64_t *id; double *box; double *conf; int32_t *cls, *age, *hits, *n_tracks, *n_new, *flags;
+    int64_t *id; double *box; double *conf; int32_t *cls, *age, *hits, *last_det, *n_tracks, *n_new, *flags;
     int cap, max_age, min_hits;
     double min_iou;
     const int32_t *slot;  // f64 path: device [S] active flags (staged); f32 path: unused
@@ -154,12 +155,12 @@ __global__ void __launch_bounds__(64) k4_update(K4Args a)
             if (lane == 0) {
                 l_box[n] = b0; l_box[cap + n] = b1; l_box[2 * cap + n] = b2; l_box[3 * cap + n] = b3;
                 l_conf[n] = dconf; l_id[n] = -(int64_t)(created + 1);
-                l_cls[n] = dcls; l_age[n] = 0; l_hits[n] = 1; l_match[n] = 1;
+                l_cls[n] = dcls; l_age[n] = 0; l_hits[n] = 1; l_match[n] = d + 1;
             }
             ++n; ++created;
         } else if (lane == 0) {  // :81-92 (class_id is not updated)
             l_box[bi] = b0; l_box[cap + bi] = b1; l_box[2 * cap + bi] = b2; l_box[3 * cap + bi] = b3;
-            l_conf[bi] = dconf; l_hits[bi] += 1; l_age[bi] = 0; l_match[bi] = 1;
+            l_conf[bi] = dconf; l_hits[bi] += 1; l_age[bi] = 0; l_match[bi] = d + 1;
         }
         __syncthreads();
     }
@@ -180,6 +181,7 @@ __global__ void __launch_bounds__(64) k4_update(K4Args a)
             double *gb = a.box + o * 4;
             gb[0] = l_box[k]; gb[1] = l_box[cap + k]; gb[2] = l_box[2 * cap + k]; gb[3] = l_box[3 * cap + k];
             a.conf[o] = l_conf[k]; a.id[o] = l_id[k]; a.cls[o] = l_cls[k]; a.age[o] = ag; a.hits[o] = l_hits[k];
+            a.last_det[o] = l_match[k] - 1;
         }
         base += __popcll(m);
     }
@@ -221,7 +223,7 @@ size_t k4_smem_bytes(int cap) { return (size_t)cap * (4 * 8 + 8 + 8 + 4 * 4) + 6
 
 int launch_update(rva_tracker *t, K4Args &a, bool f64, hipStream_t stream)
 {
-    a.id = t->id; a.box = t->box; a.conf = t->conf; a.cls = t->cls; a.age = t->age; a.hits = t->hits;
+    a.id = t->id; a.box = t->box; a.conf = t->conf; a.cls = t->cls; a.age = t->age; a.hits = t->hits; a.last_det = t->last_det;
     a.n_tracks = t->n_tracks; a.n_new = t->n_new; a.flags = t->flags;
     a.cap = t->cap; a.max_age = t->max_age; a.min_hits = t->min_hits; a.min_iou = t->min_iou;
     const size_t smem = k4_smem_bytes(t->cap);
@@ -255,6 +257,7 @@ int rva_tracker_create(rva_ctx *ctx, int n_streams, int capacity, int max_age, d
     RVA_HIP(ctx, hipMalloc(&t->cls, sc * 4));
     RVA_HIP(ctx, hipMalloc(&t->age, sc * 4));
     RVA_HIP(ctx, hipMalloc(&t->hits, sc * 4));
+    RVA_HIP(ctx, hipMalloc(&t->last_det, sc * 4));
     RVA_HIP(ctx, hipMalloc(&t->n_tracks, n_streams * 4));
     RVA_HIP(ctx, hipMalloc(&t->n_new, n_streams * 4));
     RVA_HIP(ctx, hipMalloc(&t->next_id, 8));
@@ -265,7 +268,7 @@ int rva_tracker_create(rva_ctx *ctx, int n_streams, int capacity, int max_age, d
     RVA_HIP(ctx, hipHostMalloc(&t->h_slot, n_streams * 4));
     RVA_HIP(ctx, hipHostMalloc(&t->h_offs, (n_streams + 1) * 4));
     RVA_HIP(ctx, hipEventCreateWithFlags(&t->staged, hipEventDisableTiming));
-    t->h_read_bytes = sc * (8 + 32 + 8 + 4 + 4 + 4) + n_streams * 4 + 64;
+    t->h_read_bytes = sc * (8 + 32 + 8 + 4 + 4 + 4 + 4) + n_streams * 4 + 64 * 9;
     RVA_HIP(ctx, hipHostMalloc(&t->h_read, t->h_read_bytes));
     RVA_HIP(ctx, hipMemset(t->n_tracks, 0, n_streams * 4));
     RVA_HIP(ctx, hipMemset(t->n_new, 0, n_streams * 4));
@@ -281,7 +284,7 @@ void rva_tracker_destroy(rva_tracker *t)
     if (!t) return;
     (void)hipSetDevice(t->ctx->device);
     (void)hipDeviceSynchronize();
-    void *dev[] = {t->id, t->box, t->conf, t->cls, t->age, t->hits, t->n_tracks, t->n_new, t->next_id, t->flags,
+    void *dev[] = {t->id, t->box, t->conf, t->cls, t->age, t->hits, t->last_det, t->n_tracks, t->n_new, t->next_id, t->flags,
                    t->d_slot, t->d_offs, t->d_gidx};
     for (void *p : dev) (void)hipFree(p);
     void *host[] = {t->h_slot, t->h_offs, t->h_read};
@@ -356,7 +359,7 @@ int rva_tracker_assign_ids(rva_tracker *t, const int32_t *counts_all, int n_glob
 }
 
 int rva_tracker_read_all(rva_tracker *t, int64_t *ids, int32_t *cls, int32_t *age, int32_t *hits, double *conf,
-                         double *boxes, int32_t *counts, rva_stream_t stream_)
+                         double *boxes, int32_t *last_det, int32_t *counts, rva_stream_t stream_)
 {
     if (!t) return RVA_ERR_ARG;
     hipStream_t stream = (hipStream_t)stream_;
@@ -375,6 +378,7 @@ int rva_tracker_read_all(rva_tracker *t, int64_t *ids, int32_t *cls, int32_t *ag
     size_t o_cls = off;    RVA_HIP(t->ctx, pull(cls, t->cls, sc * 4));
     size_t o_age = off;    RVA_HIP(t->ctx, pull(age, t->age, sc * 4));
     size_t o_hits = off;   RVA_HIP(t->ctx, pull(hits, t->hits, sc * 4));
+    size_t o_ld = off;     RVA_HIP(t->ctx, pull(last_det, t->last_det, sc * 4));
     size_t o_cnt = off;    RVA_HIP(t->ctx, pull(counts, t->n_tracks, (size_t)t->n_streams * 4));
     RVA_HIP(t->ctx, hipStreamSynchronize(stream));
     if (ids) std::memcpy(ids, h + o_ids, sc * 8);
@@ -383,12 +387,13 @@ int rva_tracker_read_all(rva_tracker *t, int64_t *ids, int32_t *cls, int32_t *ag
     if (cls) std::memcpy(cls, h + o_cls, sc * 4);
     if (age) std::memcpy(age, h + o_age, sc * 4);
     if (hits) std::memcpy(hits, h + o_hits, sc * 4);
+    if (last_det) std::memcpy(last_det, h + o_ld, sc * 4);
     if (counts) std::memcpy(counts, h + o_cnt, (size_t)t->n_streams * 4);
     return RVA_OK;
 }
 
 int rva_tracker_read(rva_tracker *t, int stream_id, int cap, int64_t *ids, int32_t *cls, int32_t *age, int32_t *hits,
-                     double *conf, double *boxes, int32_t *n, rva_stream_t stream_)
+                     double *conf, double *boxes, int32_t *last_det, int32_t *n, rva_stream_t stream_)
 {
     if (!t || stream_id < 0 || stream_id >= t->n_streams || !n || cap < 0) return RVA_ERR_ARG;
     hipStream_t stream = (hipStream_t)stream_;
@@ -405,6 +410,7 @@ int rva_tracker_read(rva_tracker *t, int stream_id, int cap, int64_t *ids, int32
     if (cls) RVA_HIP(t->ctx, hipMemcpyAsync(cls, t->cls + tb, (size_t)m * 4, hipMemcpyDeviceToHost, stream));
     if (age) RVA_HIP(t->ctx, hipMemcpyAsync(age, t->age + tb, (size_t)m * 4, hipMemcpyDeviceToHost, stream));
     if (hits) RVA_HIP(t->ctx, hipMemcpyAsync(hits, t->hits + tb, (size_t)m * 4, hipMemcpyDeviceToHost, stream));
+    if (last_det) RVA_HIP(t->ctx, hipMemcpyAsync(last_det, t->last_det + tb, (size_t)m * 4, hipMemcpyDeviceToHost, stream));
     RVA_HIP(t->ctx, hipStreamSynchronize(stream));
     return RVA_OK;
 }

@@ -1,0 +1,69 @@
+"""Multi-GPU glue: one process per GPU, streams sharded by rank, ONE small collective per tick.
+
+The per-stream stages never exchange data.  The only coupling in the reference is the global track
+id counter shared by all streams (tracker.py:47, shared instance pipeline.py:452,502).  To hand out
+the same ids when streams live on different GPUs, every rank all-gathers its per-stream new-track
+counts (``streams_per_rank`` int32 each -- 128 B for 32 streams) over RCCL/xGMI; each rank then
+runs the same exclusive scan in canonical stream order inside ``k4_assign_ids``.  Latency-bound
+(a few microseconds of payload), so it rides on the tick's stream right before id assignment.
+
+``backend="nccl"`` is RCCL on ROCm; ``"gloo"`` is used by the CPU tests of this logic.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: Optional[str] = None) -> tuple[int, int, int]:
+    """Read RANK / WORLD_SIZE / LOCAL_RANK (torch.distributed.run contract); returns (rank, world, local)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_streams(n_streams_total: int, rank: int, world: int) -> range:
+    """Contiguous slice of the canonical stream order owned by ``rank`` (4 per GPU for 32 streams on 8)."""
+    if n_streams_total % world:
+        raise ValueError(f"{n_streams_total} streams do not shard evenly over {world} ranks")
+    per = n_streams_total // world
+    return range(rank * per, (rank + 1) * per)
+
+
+class IdSync:
+    """All-gather of per-stream new-track counts; result is in canonical (rank-major) stream order."""
+
+    def __init__(self, streams_per_rank: int, device: torch.device, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.per = streams_per_rank
+        self.buf = torch.zeros(self.world * streams_per_rank, dtype=torch.int32, device=device)
+
+    def all_gather_counts(self, local_counts: torch.Tensor) -> torch.Tensor:
+        assert local_counts.numel() == self.per and local_counts.dtype == torch.int32
+        if self.world == 1:
+            self.buf.copy_(local_counts)
+        else:
+            dist.all_gather_into_tensor(self.buf, local_counts.contiguous(), group=self.group)
+        return self.buf
+
+
+def exclusive_id_bases(counts_all: Sequence[int], next_id: int) -> List[int]:
+    """Host statement of what k4_assign_ids computes (used by the gloo tests)."""
+    out, acc = [], next_id
+    for c in counts_all:
+        out.append(acc)
+        acc += int(c)
+    return out

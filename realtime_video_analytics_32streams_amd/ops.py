@@ -284,26 +284,29 @@ class DeviceTracker:
         cap = self.capacity
         ids = np.empty(cap, np.int64); cls = np.empty(cap, np.int32); age = np.empty(cap, np.int32)
         hits = np.empty(cap, np.int32); conf = np.empty(cap, np.float64); box = np.empty((cap, 4), np.float64)
+        ld = np.empty(cap, np.int32)
         n = C.c_int32()
         rc = N.lib().rva_tracker_read(self.handle, stream_id, cap, C.c_void_p(ids.ctypes.data), C.c_void_p(cls.ctypes.data),
                                       C.c_void_p(age.ctypes.data), C.c_void_p(hits.ctypes.data),
-                                      C.c_void_p(conf.ctypes.data), C.c_void_p(box.ctypes.data), C.byref(n), _stream_ptr())
+                                      C.c_void_p(conf.ctypes.data), C.c_void_p(box.ctypes.data),
+                                      C.c_void_p(ld.ctypes.data), C.byref(n), _stream_ptr())
         self.ctx.check(rc, "rva_tracker_read")
         m = n.value
-        return dict(n=m, id=ids[:m], cls=cls[:m], age=age[:m], hits=hits[:m], conf=conf[:m], boxes=box[:m])
+        return dict(n=m, id=ids[:m], cls=cls[:m], age=age[:m], hits=hits[:m], conf=conf[:m], boxes=box[:m],
+                    last_det=ld[:m])
 
     def read_all(self) -> List[dict]:
         S, cap = self.n_streams, self.capacity
         ids = np.empty((S, cap), np.int64); cls = np.empty((S, cap), np.int32); age = np.empty((S, cap), np.int32)
         hits = np.empty((S, cap), np.int32); conf = np.empty((S, cap), np.float64); box = np.empty((S, cap, 4), np.float64)
-        cnt = np.empty(S, np.int32)
+        cnt = np.empty(S, np.int32); ld = np.empty((S, cap), np.int32)
         rc = N.lib().rva_tracker_read_all(self.handle, C.c_void_p(ids.ctypes.data), C.c_void_p(cls.ctypes.data),
                                           C.c_void_p(age.ctypes.data), C.c_void_p(hits.ctypes.data),
                                           C.c_void_p(conf.ctypes.data), C.c_void_p(box.ctypes.data),
-                                          C.c_void_p(cnt.ctypes.data), _stream_ptr())
+                                          C.c_void_p(ld.ctypes.data), C.c_void_p(cnt.ctypes.data), _stream_ptr())
         self.ctx.check(rc, "rva_tracker_read_all")
         return [dict(n=int(cnt[s]), id=ids[s, :cnt[s]], cls=cls[s, :cnt[s]], age=age[s, :cnt[s]], hits=hits[s, :cnt[s]],
-                     conf=conf[s, :cnt[s]], boxes=box[s, :cnt[s]]) for s in range(S)]
+                     conf=conf[s, :cnt[s]], boxes=box[s, :cnt[s]], last_det=ld[s, :cnt[s]]) for s in range(S)]
 
     def state(self) -> Tuple[int, int]:
         nid = C.c_int64(); fl = C.c_int()

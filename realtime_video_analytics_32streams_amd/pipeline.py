@@ -1,0 +1,128 @@
+"""Tick-batched orchestrator for the hot path.
+
+The reference runs ``_process_packet`` once per frame per stream on one asyncio thread
+(pipeline.py:143-212): detector.predict -> filter_detections -> tracker.update.  Here one *tick*
+takes at most one frame from every stream of this GPU and runs the same order of operations for
+all of them at once, without a host round trip between the stages:
+
+    K1 pre-process (1 launch) -> detector network (PyTorch-ROCm) -> K2 decode + K3 NMS
+    -> K4 tracker update (filter_detections fused in) -> id assignment -> one read-back.
+
+Canonical order (SURVEY.md hard part 2): tick-major, streams in config order.  Skipped frames
+(``process=False``: the motion / adaptive-fps gates of pipeline.py:156-170) age the stream's tracks
+exactly like ``tracker.update(name, [])`` (pipeline.py:214-222).  A stream that delivers no frame in
+a tick is masked out and does not stall the others.
+
+Multi-GPU: each rank owns a contiguous slice of the streams; the only exchange is the per-tick
+all-gather of ``n_streams`` int32 new-track counts (RCCL) feeding ``assign_ids`` -- see
+:mod:`.dist`.
+"""
+from __future__ import annotations
+
+import time
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import ops
+from .config import PipelineConfig, StreamConfig
+from .detector import HipYoloDetector, create_detector
+from .tracker import IouTracker, Track
+from .video_stream import FramePacket, open_stream
+
+
+@dataclass
+class TickResult:
+    tick: int
+    tracks: Dict[str, List[Track]]          # per stream, every surviving track (tracker.py:95)
+    detections_emitted: Dict[str, int]      # len(filtered) of pipeline.py:187 (after F1)
+    latency_s: float
+
+
+class StreamCounters:
+    """The three per-stream counters the reference publishes (telemetry/metrics.py:55-72) as plain
+    numbers; exporting them is out of scope."""
+
+    def __init__(self):
+        self.frames_total: Dict[str, int] = {}
+        self.detections_total: Dict[str, int] = {}
+        self.active_tracks: Dict[str, int] = {}
+
+    def update(self, stream: str, frames: int, dets: int, tracks: int):
+        self.frames_total[stream] = self.frames_total.get(stream, 0) + frames
+        self.detections_total[stream] = self.detections_total.get(stream, 0) + dets
+        self.active_tracks[stream] = tracks
+
+
+class TickPipeline:
+    """All streams of one GPU, one detector, one tracker."""
+
+    def __init__(self, streams: Sequence[StreamConfig], detector: HipYoloDetector, tracker: IouTracker,
+                 sources: Optional[Sequence] = None, id_sync=None, first_global_index: int = 0,
+                 n_global_streams: Optional[int] = None):
+        self.streams = list(streams)
+        self.detector, self.tracker = detector, tracker
+        self.sources = list(sources) if sources is not None else [open_stream(s, i) for i, s in enumerate(self.streams)]
+        self.names = [s.name for s in self.streams]
+        self.slots = tracker.register_streams(self.names)
+        assert self.slots == sorted(self.slots), "streams must be registered in canonical (config) order"
+        self.counters = StreamCounters()
+        self.id_sync = id_sync
+        self.global_index = [first_global_index + i for i in range(len(self.streams))]
+        self.n_global = n_global_streams or len(self.streams)
+        self._tick = 0
+
+    @classmethod
+    def from_config(cls, cfg: PipelineConfig, **kw) -> "TickPipeline":
+        streams = [s for s in cfg.streams if s.enabled]
+        det = create_detector(cfg.detector_for(streams[0]))
+        trk = IouTracker(cfg.tracker, max_streams=max(len(streams), 1))
+        return cls(streams, det, trk, **kw)
+
+    # the device part of a tick: no host synchronisation inside --------------------------------------
+    def enqueue(self, packets: Sequence[Optional[FramePacket]], process: Optional[Sequence[bool]] = None):
+        live = [(i, p) for i, p in enumerate(packets) if p is not None and (process is None or process[i])]
+        n_s = self.tracker.device_tracker.n_streams
+        slot_of_stream = [-1] * n_s
+        post = None
+        if live:
+            post = self.detector.predict_batch_device([p for _, p in live])
+            for row, (i, _) in enumerate(live):
+                slot_of_stream[self.slots[i]] = row
+        for i, p in enumerate(packets):
+            if p is not None and process is not None and not process[i]:
+                slot_of_stream[self.slots[i]] = -2       # skipped frame: ages the tracks
+        dev = self.tracker.device_tracker
+        dev.update_from_post(slot_of_stream, post, self.detector.config.confidence_threshold)
+        if self.id_sync is None:
+            dev.assign_ids()
+        else:
+            counts_all = self.id_sync.all_gather_counts(dev.new_counts_tensor()[:len(self.streams)])
+            dev.assign_ids(counts_all, self.global_index + [0] * (n_s - len(self.streams)))
+        return post
+
+    def tick(self, process: Optional[Sequence[bool]] = None) -> TickResult:
+        t0 = time.perf_counter()
+        packets = [src.next_packet() for src in self.sources]
+        post = self.enqueue(packets, process)
+        tables = self.tracker.device_tracker.read_all()          # the one host sync of the tick
+        names = [n for n, p in zip(self.names, packets) if p is not None]
+        tabs = [tables[self.slots[i]] for i, p in enumerate(packets) if p is not None]
+        tracks = dict(zip(names, self.tracker.tracks_from_tables(names, tabs)))
+        emitted = {}
+        if post is not None:
+            # len(filtered): detections that survive filter_detections (float64 compare on widened scores)
+            counts = post.counts.cpu().numpy()
+            thr = self.detector.config.confidence_threshold
+            scores = post.scores[:, :max(int(counts.max()), 1)].double().cpu().numpy()
+            row = 0
+            for i, p in enumerate(packets):
+                if p is None or (process is not None and not process[i]):
+                    continue
+                emitted[self.names[i]] = int((scores[row, :counts[row]] >= thr).sum())
+                row += 1
+        for n in names:
+            self.counters.update(n, 1, emitted.get(n, 0), len(tracks[n]))
+        self._tick += 1
+        return TickResult(self._tick - 1, tracks, emitted, time.perf_counter() - t0)
