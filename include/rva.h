@@ -178,6 +178,15 @@ int rva_tracker_read_all(rva_tracker *trk, int64_t *ids, int32_t *cls, int32_t *
                          double *conf, double *boxes, int32_t *last_det, int32_t *counts,
                          rva_stream_t stream);
 
+/* Pipelined read-back: snapshot_async enqueues device-to-host copies of every table into pinned
+ * staging slot 0 or 1 on `stream` (no host wait); snapshot_fetch waits for that slot's copies only
+ * and hands the arrays out ([n_streams, capacity(,4)] like read_all).  Lets tick k+1 be enqueued
+ * before tick k's tracks are consumed. */
+int rva_tracker_snapshot_async(rva_tracker *trk, int slot, rva_stream_t stream);
+int rva_tracker_snapshot_fetch(rva_tracker *trk, int slot, int64_t *ids, int32_t *cls, int32_t *age,
+                               int32_t *hits, double *conf, double *boxes, int32_t *last_det,
+                               int32_t *counts);
+
 /* Host-synchronous: next id the counter will hand out; flags bit 0 = a table overflowed `capacity`. */
 int rva_tracker_state(rva_tracker *trk, int64_t *next_id, int *flags, rva_stream_t stream);
 int rva_tracker_set_next_id(rva_tracker *trk, int64_t next_id, rva_stream_t stream);

@@ -108,6 +108,8 @@ def lib() -> C.CDLL:
         "rva_tracker_assign_ids": (C.c_int, [_P, _P, C.c_int, i32p, _P]),
         "rva_tracker_read": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, i32p, _P]),
         "rva_tracker_read_all": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+        "rva_tracker_snapshot_async": (C.c_int, [_P, C.c_int, _P]),
+        "rva_tracker_snapshot_fetch": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
         "rva_tracker_state": (C.c_int, [_P, i64p, C.POINTER(C.c_int), _P]),
         "rva_tracker_set_next_id": (C.c_int, [_P, C.c_int64, _P]),
         "rva_decode_available": (C.c_int, [C.c_char_p, C.c_int]),
@@ -127,7 +129,8 @@ EXPORTS = [
     "rva_preprocess_nv12_batch", "rva_preprocess_bgr_batch", "rva_preprocess_clip_nv12_batch",
     "rva_preprocess_clip_bgr_batch", "rva_postprocess_batch", "rva_post_status", "rva_tracker_create",
     "rva_tracker_destroy", "rva_tracker_update_f32", "rva_tracker_update_f64", "rva_tracker_new_counts",
-    "rva_tracker_assign_ids", "rva_tracker_read", "rva_tracker_read_all", "rva_tracker_state",
+    "rva_tracker_assign_ids", "rva_tracker_read", "rva_tracker_read_all", "rva_tracker_snapshot_async",
+    "rva_tracker_snapshot_fetch", "rva_tracker_state",
     "rva_tracker_set_next_id", "rva_decode_available",
 ]
 

@@ -34,14 +34,16 @@ struct rva_tracker {
     int32_t *last_det = nullptr;  // [S][cap] index of the last detection of the latest update that wrote the row, -1 if none
     int32_t *n_tracks = nullptr;  // [S]
     int32_t *n_new = nullptr;     // [S]
-    int64_t *next_id = nullptr;   // [1]
+    int64_t *next_id = nullptr;   // [1] the reference's itertools.count(1) (tracker.py:47)
+    int32_t *id_ticket = nullptr; // [1] arrival counter of k4_assign_ids (returns to 0 every launch)
     int32_t *flags = nullptr;     // [1]
     int32_t *d_slot = nullptr;    // [S] per-tick: slot / active
     int32_t *d_offs = nullptr;    // [S+1]
     int32_t *d_gidx = nullptr;    // [S]
     // pinned host staging
     int32_t *h_slot = nullptr, *h_offs = nullptr;
-    void *h_read = nullptr;
+    void *h_read[2] = {nullptr, nullptr};   // pinned snapshot slots
+    hipEvent_t snap_done[2] = {nullptr, nullptr};
     size_t h_read_bytes = 0;
     hipEvent_t staged = nullptr;  // completion of the last async copy out of h_slot/h_offs
     std::vector<int32_t> gidx_cached;
@@ -192,31 +194,44 @@ __global__ void __launch_bounds__(64) k4_update(K4Args a)
     }
 }
 
-// One block.  counts_all[n_global] in canonical order; local stream s sits at gidx[s].
-__global__ void __launch_bounds__(256) k4_assign_ids(int64_t *id, const int32_t *n_tracks, const int32_t *counts_all,
-                                                     int n_global, const int32_t *gidx, int n_streams, int cap,
-                                                     int64_t *next_id)
+// One block per local stream.  counts_all[n_global] in canonical order; local stream s sits at
+// gidx[s].  Every block reads the id counter, then takes a ticket; the LAST block to arrive advances
+// the counter (so no block can read the advanced value) and re-arms the ticket: safe under any
+// dispatch order and identical on every replay of a captured graph.
+__global__ void __launch_bounds__(64) k4_assign_ids(int64_t *id, const int32_t *n_tracks, const int32_t *counts_all,
+                                                    int n_global, const int32_t *gidx, int cap,
+                                                    int64_t *next_id, int32_t *ticket)
 {
-    __shared__ long long s_total;
-    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
-    long long *prefix = (long long *)sm;  // [n_global] exclusive prefix
-    if (threadIdx.x == 0) {
-        long long acc = 0;
-        for (int g = 0; g < n_global; ++g) { prefix[g] = acc; acc += counts_all[g]; }
-        s_total = acc;
+    const int s = blockIdx.x, lane = threadIdx.x;
+    const int g = gidx ? gidx[s] : s;
+    long long before = 0, total = 0;   // exclusive prefix at g, and the grand total
+    for (int i = lane; i < n_global; i += 64) {
+        const long long c = counts_all[i];
+        total += c;
+        if (i < g) before += c;
     }
-    __syncthreads();
-    const long long first = *next_id;
-    for (int s = 0; s < n_streams; ++s) {
-        const long long b = first + prefix[gidx ? gidx[s] : s];
-        const int n = n_tracks[s];
-        for (int k = threadIdx.x; k < n; k += blockDim.x) {
-            const long long v = id[(size_t)s * cap + k];
-            if (v < 0) id[(size_t)s * cap + k] = b + (-v - 1);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        before += __shfl_xor(before, off);
+        total += __shfl_xor(total, off);
+    }
+    const long long first = __hip_atomic_load(next_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const long long b = first + before;
+    const int n = n_tracks[s];
+    // provisional ids are only ever at the tail of the table (new rows are appended)
+    for (int k = n - 1 - lane; k >= 0; k -= 64) {
+        const long long v = id[(size_t)s * cap + k];
+        const bool neg = v < 0;
+        if (neg) id[(size_t)s * cap + k] = b + (-v - 1);
+        if (!__any(neg)) break;
+    }
+    if (lane == 0) {
+        __threadfence();  // the counter read above is complete before the ticket is taken
+        if (atomicAdd(ticket, 1) == (int)gridDim.x - 1) {
+            __hip_atomic_store(next_id, first + total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    __syncthreads();
-    if (threadIdx.x == 0) *next_id = first + s_total;
 }
 
 size_t k4_smem_bytes(int cap) { return (size_t)cap * (4 * 8 + 8 + 8 + 4 * 4) + 64; }
@@ -261,6 +276,8 @@ int rva_tracker_create(rva_ctx *ctx, int n_streams, int capacity, int max_age, d
     RVA_HIP(ctx, hipMalloc(&t->n_tracks, n_streams * 4));
     RVA_HIP(ctx, hipMalloc(&t->n_new, n_streams * 4));
     RVA_HIP(ctx, hipMalloc(&t->next_id, 8));
+    RVA_HIP(ctx, hipMalloc(&t->id_ticket, 4));
+    RVA_HIP(ctx, hipMemset(t->id_ticket, 0, 4));
     RVA_HIP(ctx, hipMalloc(&t->flags, 4));
     RVA_HIP(ctx, hipMalloc(&t->d_slot, n_streams * 4));
     RVA_HIP(ctx, hipMalloc(&t->d_offs, (n_streams + 1) * 4));
@@ -269,7 +286,10 @@ int rva_tracker_create(rva_ctx *ctx, int n_streams, int capacity, int max_age, d
     RVA_HIP(ctx, hipHostMalloc(&t->h_offs, (n_streams + 1) * 4));
     RVA_HIP(ctx, hipEventCreateWithFlags(&t->staged, hipEventDisableTiming));
     t->h_read_bytes = sc * (8 + 32 + 8 + 4 + 4 + 4 + 4) + n_streams * 4 + 64 * 9;
-    RVA_HIP(ctx, hipHostMalloc(&t->h_read, t->h_read_bytes));
+    for (int i = 0; i < 2; ++i) {
+        RVA_HIP(ctx, hipHostMalloc(&t->h_read[i], t->h_read_bytes));
+        RVA_HIP(ctx, hipEventCreateWithFlags(&t->snap_done[i], hipEventDisableTiming));
+    }
     RVA_HIP(ctx, hipMemset(t->n_tracks, 0, n_streams * 4));
     RVA_HIP(ctx, hipMemset(t->n_new, 0, n_streams * 4));
     RVA_HIP(ctx, hipMemset(t->flags, 0, 4));
@@ -284,10 +304,11 @@ void rva_tracker_destroy(rva_tracker *t)
     if (!t) return;
     (void)hipSetDevice(t->ctx->device);
     (void)hipDeviceSynchronize();
-    void *dev[] = {t->id, t->box, t->conf, t->cls, t->age, t->hits, t->last_det, t->n_tracks, t->n_new, t->next_id, t->flags,
+    void *dev[] = {t->id, t->box, t->conf, t->cls, t->age, t->hits, t->last_det, t->n_tracks, t->n_new, t->next_id, t->id_ticket, t->flags,
                    t->d_slot, t->d_offs, t->d_gidx};
     for (void *p : dev) (void)hipFree(p);
-    void *host[] = {t->h_slot, t->h_offs, t->h_read};
+    void *host[] = {t->h_slot, t->h_offs, t->h_read[0], t->h_read[1]};
+    for (int i = 0; i < 2; ++i) if (t->snap_done[i]) (void)hipEventDestroy(t->snap_done[i]);
     for (void *p : host) (void)hipHostFree(p);
     if (t->staged) (void)hipEventDestroy(t->staged);
     delete t;
@@ -352,44 +373,60 @@ int rva_tracker_assign_ids(rva_tracker *t, const int32_t *counts_all, int n_glob
     } else if (n_global != t->n_streams) {
         return rva_fail(t->ctx, RVA_ERR_ARG, "global_index required when n_global != n_streams");
     }
-    k4_assign_ids<<<1, 256, (size_t)n_global * 8, stream>>>(t->id, t->n_tracks, counts_all, n_global, gidx,
-                                                            t->n_streams, t->cap, t->next_id);
+    k4_assign_ids<<<t->n_streams, 64, 0, stream>>>(t->id, t->n_tracks, counts_all, n_global, gidx, t->cap,
+                                                   t->next_id, t->id_ticket);
     RVA_HIP(t->ctx, hipGetLastError());
+    return RVA_OK;
+}
+
+// Snapshot layout inside a pinned slot: fixed offsets, 64-byte aligned sections.
+static size_t snap_off(const rva_tracker *t, int section)
+{
+    const size_t sc = (size_t)t->n_streams * t->cap;
+    const size_t sizes[8] = {sc * 8, sc * 32, sc * 8, sc * 4, sc * 4, sc * 4, sc * 4, (size_t)t->n_streams * 4};
+    size_t off = 0;
+    for (int i = 0; i < section; ++i) off += (sizes[i] + 63) & ~(size_t)63;
+    return off;
+}
+
+int rva_tracker_snapshot_async(rva_tracker *t, int slot, rva_stream_t stream_)
+{
+    if (!t || slot < 0 || slot > 1) return RVA_ERR_ARG;
+    hipStream_t stream = (hipStream_t)stream_;
+    const size_t sc = (size_t)t->n_streams * t->cap;
+    char *h = (char *)t->h_read[slot];
+    const void *src[8] = {t->id, t->box, t->conf, t->cls, t->age, t->hits, t->last_det, t->n_tracks};
+    const size_t sizes[8] = {sc * 8, sc * 32, sc * 8, sc * 4, sc * 4, sc * 4, sc * 4, (size_t)t->n_streams * 4};
+    for (int i = 0; i < 8; ++i)
+        RVA_HIP(t->ctx, hipMemcpyAsync(h + snap_off(t, i), src[i], sizes[i], hipMemcpyDeviceToHost, stream));
+    RVA_HIP(t->ctx, hipEventRecord(t->snap_done[slot], stream));
+    return RVA_OK;
+}
+
+int rva_tracker_snapshot_fetch(rva_tracker *t, int slot, int64_t *ids, int32_t *cls, int32_t *age, int32_t *hits,
+                               double *conf, double *boxes, int32_t *last_det, int32_t *counts)
+{
+    if (!t || slot < 0 || slot > 1) return RVA_ERR_ARG;
+    RVA_HIP(t->ctx, hipEventSynchronize(t->snap_done[slot]));
+    const size_t sc = (size_t)t->n_streams * t->cap;
+    const char *h = (const char *)t->h_read[slot];
+    if (ids) std::memcpy(ids, h + snap_off(t, 0), sc * 8);
+    if (boxes) std::memcpy(boxes, h + snap_off(t, 1), sc * 32);
+    if (conf) std::memcpy(conf, h + snap_off(t, 2), sc * 8);
+    if (cls) std::memcpy(cls, h + snap_off(t, 3), sc * 4);
+    if (age) std::memcpy(age, h + snap_off(t, 4), sc * 4);
+    if (hits) std::memcpy(hits, h + snap_off(t, 5), sc * 4);
+    if (last_det) std::memcpy(last_det, h + snap_off(t, 6), sc * 4);
+    if (counts) std::memcpy(counts, h + snap_off(t, 7), (size_t)t->n_streams * 4);
     return RVA_OK;
 }
 
 int rva_tracker_read_all(rva_tracker *t, int64_t *ids, int32_t *cls, int32_t *age, int32_t *hits, double *conf,
                          double *boxes, int32_t *last_det, int32_t *counts, rva_stream_t stream_)
 {
-    if (!t) return RVA_ERR_ARG;
-    hipStream_t stream = (hipStream_t)stream_;
-    const size_t sc = (size_t)t->n_streams * t->cap;
-    char *h = (char *)t->h_read;
-    size_t off = 0;
-    auto pull = [&](void *dst, const void *src, size_t bytes) -> hipError_t {
-        if (!dst) return hipSuccess;
-        hipError_t e = hipMemcpyAsync(h + off, src, bytes, hipMemcpyDeviceToHost, stream);
-        off += (bytes + 63) & ~(size_t)63;
-        return e;
-    };
-    size_t o_ids = off;    RVA_HIP(t->ctx, pull(ids, t->id, sc * 8));
-    size_t o_box = off;    RVA_HIP(t->ctx, pull(boxes, t->box, sc * 32));
-    size_t o_conf = off;   RVA_HIP(t->ctx, pull(conf, t->conf, sc * 8));
-    size_t o_cls = off;    RVA_HIP(t->ctx, pull(cls, t->cls, sc * 4));
-    size_t o_age = off;    RVA_HIP(t->ctx, pull(age, t->age, sc * 4));
-    size_t o_hits = off;   RVA_HIP(t->ctx, pull(hits, t->hits, sc * 4));
-    size_t o_ld = off;     RVA_HIP(t->ctx, pull(last_det, t->last_det, sc * 4));
-    size_t o_cnt = off;    RVA_HIP(t->ctx, pull(counts, t->n_tracks, (size_t)t->n_streams * 4));
-    RVA_HIP(t->ctx, hipStreamSynchronize(stream));
-    if (ids) std::memcpy(ids, h + o_ids, sc * 8);
-    if (boxes) std::memcpy(boxes, h + o_box, sc * 32);
-    if (conf) std::memcpy(conf, h + o_conf, sc * 8);
-    if (cls) std::memcpy(cls, h + o_cls, sc * 4);
-    if (age) std::memcpy(age, h + o_age, sc * 4);
-    if (hits) std::memcpy(hits, h + o_hits, sc * 4);
-    if (last_det) std::memcpy(last_det, h + o_ld, sc * 4);
-    if (counts) std::memcpy(counts, h + o_cnt, (size_t)t->n_streams * 4);
-    return RVA_OK;
+    int rc = rva_tracker_snapshot_async(t, 0, stream_);
+    if (rc != RVA_OK) return rc;
+    return rva_tracker_snapshot_fetch(t, 0, ids, cls, age, hits, conf, boxes, last_det, counts);
 }
 
 int rva_tracker_read(rva_tracker *t, int stream_id, int cap, int64_t *ids, int32_t *cls, int32_t *age, int32_t *hits,

@@ -295,6 +295,22 @@ class DeviceTracker:
         return dict(n=m, id=ids[:m], cls=cls[:m], age=age[:m], hits=hits[:m], conf=conf[:m], boxes=box[:m],
                     last_det=ld[:m])
 
+    def snapshot_async(self, slot: int) -> None:
+        self.ctx.check(N.lib().rva_tracker_snapshot_async(self.handle, slot, _stream_ptr()), "rva_tracker_snapshot_async")
+
+    def snapshot_fetch(self, slot: int) -> List[dict]:
+        S, cap = self.n_streams, self.capacity
+        ids = np.empty((S, cap), np.int64); cls = np.empty((S, cap), np.int32); age = np.empty((S, cap), np.int32)
+        hits = np.empty((S, cap), np.int32); conf = np.empty((S, cap), np.float64); box = np.empty((S, cap, 4), np.float64)
+        cnt = np.empty(S, np.int32); ld = np.empty((S, cap), np.int32)
+        rc = N.lib().rva_tracker_snapshot_fetch(self.handle, slot, C.c_void_p(ids.ctypes.data), C.c_void_p(cls.ctypes.data),
+                                                C.c_void_p(age.ctypes.data), C.c_void_p(hits.ctypes.data),
+                                                C.c_void_p(conf.ctypes.data), C.c_void_p(box.ctypes.data),
+                                                C.c_void_p(ld.ctypes.data), C.c_void_p(cnt.ctypes.data))
+        self.ctx.check(rc, "rva_tracker_snapshot_fetch")
+        return [dict(n=int(cnt[s]), id=ids[s, :cnt[s]], cls=cls[s, :cnt[s]], age=age[s, :cnt[s]], hits=hits[s, :cnt[s]],
+                     conf=conf[s, :cnt[s]], boxes=box[s, :cnt[s]], last_det=ld[s, :cnt[s]]) for s in range(S)]
+
     def read_all(self) -> List[dict]:
         S, cap = self.n_streams, self.capacity
         ids = np.empty((S, cap), np.int64); cls = np.empty((S, cap), np.int32); age = np.empty((S, cap), np.int32)

@@ -1,0 +1,190 @@
+"""API-level parity on the GPU: the reference-shaped classes (HipYoloDetector / IouTracker /
+TickPipeline / HipCNNLSTMDetector) driven the way the reference's plugin API is driven."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+from realtime_video_analytics_32streams_amd import ops, synth
+from realtime_video_analytics_32streams_amd.config import DetectorConfig, StreamConfig, TrackerConfig
+from realtime_video_analytics_32streams_amd.detector import Detection, HipYoloDetector, create_detector, filter_detections
+from realtime_video_analytics_32streams_amd.pipeline import TickPipeline
+from realtime_video_analytics_32streams_amd.temporal import CnnLstmNet, HipCNNLSTMDetector, TemporalDetection
+from realtime_video_analytics_32streams_amd.tracker import IouTracker, Track
+from realtime_video_analytics_32streams_amd.video_stream import FramePacket, SyntheticNv12Stream
+from realtime_video_analytics_32streams_amd.yolov8 import build_detector_net, calibrate_detection_density
+from tests.conftest import load_golden
+from tests.helpers import head_for_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(**kw):
+    base = dict(model_path="yolov8n.pt", backend="hip", model_type="yolov8", warmup=False)
+    base.update(kw)
+    return DetectorConfig(**base)
+
+
+@pytest.mark.parametrize("idx", [0, 2, 4, 5, 9])
+def test_detector_predict_returns_reference_detections(idx):
+    """predict(packet) with the network stubbed by the recorded head (the reference's _infer stub
+    point): Detection objects must equal what the reference's _postprocess returned."""
+    case = load_golden("post_cases.json")["cases"][idx]
+    raw = torch.from_numpy(head_for_case(case)).cuda()[None]
+    w, h = case["orig_wh"]
+    det = HipYoloDetector(_cfg(confidence_threshold=case["conf"], iou_threshold=case["iou"], classes=case["classes"]),
+                          infer_fn=lambda t: raw)
+    frame = synth.make_bgr(1, w, h) if (w % 2 or h % 2) else None
+    if frame is None:
+        y, uv = synth.make_nv12(1, w, h)
+        frame = ops.Nv12Surface.from_numpy(y, uv, w, h)
+    pkt = FramePacket(stream=StreamConfig(name="cam", url="x"), frame=frame, frame_id=7, timestamp=0.0)
+    dets = det.predict(pkt)
+    exp = case["expect"]
+    assert all(isinstance(d, Detection) and d.stream_name == "cam" and d.frame_id == 7 for d in dets)
+    assert [d.class_id for d in dets] == exp["cls"]
+    assert [d.confidence for d in dets] == exp["conf"]
+    assert [list(d.bbox_xyxy) for d in dets] == exp["boxes"]
+    assert all(type(d.confidence) is float and type(d.class_id) is int for d in dets)
+
+
+def test_tracker_api_inline_probes(tracker_cases):
+    for probe in tracker_cases["inline"]:
+        trk = IouTracker(TrackerConfig(**probe["cfg"]), max_streams=4, capacity=64)
+        for t, step in enumerate(probe["steps"]):
+            dets = [Detection(step["stream"], t, int(k), float(c), tuple(b))
+                    for b, c, k in zip(step["boxes"], step["conf"], step["cls"])]
+            tracks = trk.update(step["stream"], dets)
+            assert all(isinstance(x, Track) for x in tracks)
+            got = [[x.track_id, x.class_id, x.age, x.hits, x.confidence, list(x.bbox_xyxy)] for x in tracks]
+            assert got == step["table"], probe["name"]
+
+
+def test_tracker_returns_aliased_track_objects():
+    trk = IouTracker(TrackerConfig(max_age=30, max_iou_distance=0.5, min_hits=1), max_streams=2, capacity=64)
+    a = trk.update("s", [Detection("s", 0, 1, 0.9, (0.0, 0.0, 100.0, 100.0))])
+    b = trk.update("s", [Detection("s", 1, 1, 0.8, (2.0, 2.0, 100.0, 100.0))])
+    assert a[0] is b[0] and a[0].hits == 2 and a[0].confidence == 0.8    # tracker state is live, as in the reference
+
+
+def test_tracker_carries_temporal_fields():
+    trk = IouTracker(TrackerConfig(max_age=30, max_iou_distance=0.5, min_hits=1), max_streams=2, capacity=64)
+    d = TemporalDetection("s", 31, 3, 0.9, (0.0, 0.0, 3840.0, 2160.0), action_label="run", temporal_score=0.9,
+                          sequence_start_frame=0, sequence_end_frame=31)
+    t = trk.update("s", [d])[0]
+    assert (t.action_label, t.temporal_score, t.sequence_start_frame, t.sequence_end_frame) == ("run", 0.9, 0, 31)
+    d2 = TemporalDetection("s", 39, 3, 0.7, (0.0, 0.0, 3840.0, 2160.0), action_label="walk", temporal_score=0.7,
+                           sequence_start_frame=8, sequence_end_frame=39)
+    t2 = trk.update("s", [d2])[0]
+    assert t2 is t and t.action_label == "walk" and t.sequence_end_frame == 39 and t.hits == 2
+
+
+def _make_pipe(n_streams, scale="n", seed=0):
+    streams = [StreamConfig(name=f"cam{i}", url="synthetic://1920x1080", warmup_seconds=0.0) for i in range(n_streams)]
+    det = HipYoloDetector(_cfg(half=True, confidence_threshold=0.25), net=build_detector_net(scale, seed=seed))
+    srcs = [SyntheticNv12Stream(s, index=i, n_unique=3) for i, s in enumerate(streams)]
+    for s in srcs:
+        s.open_sync()
+    with torch.inference_mode():
+        sample, _ = ops.preprocess_nv12([s._ring[0] for s in srcs], (640, 640), half=True)
+    calibrate_detection_density(det.net, sample.contiguous(memory_format=torch.channels_last), 0.25, 80)
+    trk = IouTracker(TrackerConfig(max_age=5, max_iou_distance=0.5, min_hits=1), max_streams=n_streams, capacity=512)
+    return streams, det, trk, srcs
+
+
+def test_tick_pipeline_equals_per_stream_reference_order():
+    """A batched tick must give the tracks (ids included) of the reference's per-frame loop:
+    for each stream in config order: predict -> filter_detections -> update.
+    MIOpen's split-K convolutions accumulate with atomics, so the network output is not bit-stable
+    across batch compositions; both sides therefore consume the SAME head tensor (recorded from the
+    tick), which is the boundary all downstream parity is defined at."""
+    streams, det, trk, srcs = _make_pipe(4)
+    pipe = TickPipeline(streams, det, trk, sources=srcs)
+    rec = {}
+    net = det.net
+    det._infer_fn = lambda t: rec.setdefault("raw", net(t.contiguous(memory_format=torch.channels_last)))
+    trk2 = IouTracker(TrackerConfig(max_age=5, max_iou_distance=0.5, min_hits=1), max_streams=4, capacity=512)
+    srcs2 = [SyntheticNv12Stream(s, index=i, n_unique=3) for i, s in enumerate(streams)]
+    total = 0
+    for _ in range(6):
+        rec.clear()
+        res = pipe.tick()
+        raw = rec["raw"]
+        for i, (s, src) in enumerate(zip(streams, srcs2)):
+            one = HipYoloDetector(det.config, infer_fn=lambda t, i=i: raw[i:i + 1].clone())
+            dets = one.predict(src.next_packet())                        # batch-of-one reference API
+            kept = filter_detections(dets, det.config.confidence_threshold)
+            want = trk2.update(s.name, kept)
+            got = res.tracks[s.name]
+            assert [(t.track_id, t.class_id, t.age, t.hits, t.confidence, t.bbox_xyxy) for t in got] == \
+                   [(t.track_id, t.class_id, t.age, t.hits, t.confidence, t.bbox_xyxy) for t in want]
+            assert res.detections_emitted[s.name] == len(kept)
+            total += len(got)
+    assert total > 0
+
+
+def test_tick_pipeline_skipped_and_missing_frames():
+    streams, det, trk, srcs = _make_pipe(3)
+    srcs[2].n_frames = 2                                  # stream 2 runs dry after two frames
+    pipe = TickPipeline(streams, det, trk, sources=srcs)
+    r0 = pipe.tick()
+    n0 = {k: len(v) for k, v in r0.tracks.items()}
+    r1 = pipe.tick(process=[True, False, True])           # stream 1's frame is gated out: update(name, [])
+    assert all(t.age == 1 for t in r1.tracks["cam1"]) and len(r1.tracks["cam1"]) == n0["cam1"]
+    r2 = pipe.tick()
+    assert "cam2" not in r2.tracks and set(r2.tracks) == {"cam0", "cam1"}   # dry stream masked, others unaffected
+
+
+def test_detector_self_parity_fp16_gpu_vs_fp32_cpu():
+    """No reference weights/ORT exist offline: the network is checked against ITSELF (CPU fp32)."""
+    net = build_detector_net("n", seed=0)
+    ref = copy.deepcopy(net).fuse().float()
+    det = HipYoloDetector(_cfg(half=True), net=net)
+    y, uv = synth.make_nv12(3, 1920, 1080)
+    t, _ = ops.preprocess_nv12([ops.Nv12Surface.from_numpy(y, uv, 1920, 1080)], (640, 640), half=True)
+    with torch.inference_mode():
+        got = det._infer(t).float().cpu()
+        want = ref(t.float().cpu())
+    assert got.shape == want.shape == (1, 84, 8400)
+    assert (got[:, :4] - want[:, :4]).abs().max() < 2.0          # pixels (fp16 accumulation of DFL boxes)
+    assert (got[:, 4:] - want[:, 4:]).abs().max() < 2e-2         # class probabilities
+
+
+def test_create_detector_dispatch():
+    assert isinstance(create_detector(_cfg()), HipYoloDetector)
+    assert isinstance(create_detector(_cfg(model_type="cnn_lstm", model_path="x.onnx", sequence_length=4)), HipCNNLSTMDetector)
+    with pytest.raises(ValueError):
+        create_detector(_cfg(model_type="3d_cnn", model_path="x.onnx"))
+
+
+def test_cnn_lstm_detector_clips_and_scores():
+    """BASELINE config 5 shape in miniature: L=4, stride=2, overlap=0.5 on 4K NV12 frames; schedule and
+    top-5 rule against a CPU fp32 run of the same network on oracle-preprocessed frames."""
+    cfg = _cfg(model_type="cnn_lstm", model_path="x.onnx", sequence_length=4, sequence_stride=2, temporal_overlap=0.5,
+               confidence_threshold=-1e9, num_action_classes=400, input_size=[224, 224],
+               action_classes=[f"a{i}" for i in range(400)])
+    torch.manual_seed(1)
+    net = CnnLstmNet(400).eval()
+    det = HipCNNLSTMDetector(cfg, net=copy.deepcopy(net))
+    st = StreamConfig(name="cam", url="x")
+    frames = [synth.make_nv12(40 + f, 3840, 2160, tick=f) for f in range(12)]
+    fired = {}
+    for f, (y, uv) in enumerate(frames):
+        out = det.predict(FramePacket(st, ops.Nv12Surface.from_numpy(y, uv, 3840, 2160), f, 0.0))
+        if out:
+            fired[f] = out
+    assert sorted(fired) == [7, 9, 11]                      # need = 8 frames, step = 2
+    clip_ids = [0, 2, 4, 6]
+    x = np.stack([orc.preprocess_clip_frame(nv12=frames[i], wh=(3840, 2160), tw=224, th=224, half=False) for i in clip_ids])
+    with torch.inference_mode():
+        want = net(torch.from_numpy(x)[None]).flatten().numpy()
+    dets = fired[7]
+    assert len(dets) == 5 and all(isinstance(d, TemporalDetection) for d in dets)
+    top = np.argsort(want)[-5:][::-1]
+    assert [d.class_id for d in dets] == top.tolist()
+    assert np.allclose([d.confidence for d in dets], want[top], atol=1e-3)     # float tolerance for the network only
+    d = dets[0]
+    assert d.bbox_xyxy == (0.0, 0.0, 3840.0, 2160.0) and d.frame_id == 6 and d.sequence_start_frame == 0
+    assert d.sequence_end_frame == 6 and d.action_label == f"a{d.class_id}" and d.temporal_score == d.confidence
