@@ -192,6 +192,36 @@ int rva_tracker_state(rva_tracker *trk, int64_t *next_id, int *flags, rva_stream
 int rva_tracker_set_next_id(rva_tracker *trk, int64_t next_id, rva_stream_t stream);
 
 /* ----------------------------------------------------------------------------------------------
+ * Fused detector primitives (NHWC float16) -- the arithmetic ONNX Runtime performs inside
+ * `session.run` (detector.py:608) for a YOLOv8 graph, one pass per layer instead of MIOpen's
+ * conv + bias + SiLU + concat chains.  Activations are [batch*H*W, channels] with a row stride
+ * (ld, in elements) so layers read / write channel slices of shared concat buffers.
+ *
+ * rva_conv2d_nhwc_f16: out = [SiLU](conv(in, weights) + bias) [+ residual]; ksize 1 or 3 (pad ksize/2),
+ *   stride 1 or 2, Cin % 8 == 0, Cout % 8 == 0.  weights: float16 [rva_conv_cout_pad(Cout)][ksize*ksize][CinPad]
+ *   with CinPad = Cin rounded up to 32 (padding rows / channels zero), bias: float32 [rva_conv_cout_pad(Cout)].
+ *   MFMA implicit GEMM, fp32 accumulate.
+ * rva_stem_conv_f16: first layer, 3x3 stride 2 on the PLANAR tensor K1 writes ([batch,3,H,W]);
+ *   weights float32 [Cout][27] in (c,ky,kx) order; output NHWC.
+ * rva_maxpool5_nhwc_f16 / rva_upsample2x_nhwc_f16: SPPF pooling, FPN nearest upsample, on channel slices.
+ * rva_yolo_head_f16: DFL expectation + dist2bbox + sigmoid of one pyramid level into
+ *   out[batch, 4+nc, anchors_total] at anchor_offset -- the `[B,84,8400]` tensor rva_postprocess_batch reads.
+ * -------------------------------------------------------------------------------------------- */
+int rva_conv_cout_pad(int Cout);
+int rva_conv2d_nhwc_f16(rva_ctx *ctx, const void *in, int ldi, const void *weights, const float *bias,
+                        void *out, int ldo, const void *residual, int ldr, int batch, int H, int W, int Cin,
+                        int Cout, int ksize, int stride, int act, rva_stream_t stream);
+int rva_stem_conv_f16(rva_ctx *ctx, const void *in_planar, const float *weights, const float *bias,
+                      void *out, int ldo, int batch, int H, int W, int Cout, rva_stream_t stream);
+int rva_maxpool5_nhwc_f16(rva_ctx *ctx, const void *in, int ldi, void *out, int ldo, int batch, int H,
+                          int W, int C, rva_stream_t stream);
+int rva_upsample2x_nhwc_f16(rva_ctx *ctx, const void *in, int ldi, void *out, int ldo, int batch, int H,
+                            int W, int C, rva_stream_t stream);
+int rva_yolo_head_f16(rva_ctx *ctx, const void *box_logits, int ldb, const void *cls_logits, int ldc,
+                      void *out, int batch, int h, int w, int nc, int anchors_total, int anchor_offset,
+                      float stride, rva_stream_t stream);
+
+/* ----------------------------------------------------------------------------------------------
  * Decode probe -- stands where VideoStream.open() (video_stream.py:61-95) sits.  librocdecode is
  * looked up with dlopen at run time; RVA_ERR_UNAVAILABLE if the machine does not have it.
  * -------------------------------------------------------------------------------------------- */

@@ -1,0 +1,453 @@
+// Fused detector primitives (NHWC fp16) for the YOLOv8 network of the hot path.
+//
+// Why these exist: profiling the PyTorch/MIOpen network (profiles/r01_a_*) shows four kernels per
+// convolution (zero-fill for split-K atomics, implicit GEMM, broadcast bias add, SiLU) plus chunk /
+// concat copies; only ~40 % of the detector time is MFMA work and most layers are HBM-bound at
+// YOLOv8 channel widths.  The kernels here do one pass per layer:
+//
+//   k_conv_mfma<BN,WPX,KS>  implicit-GEMM convolution, 1x1 or 3x3 (stride 1/2, pad KS/2) on
+//       v_mfma_f32_16x16x32_f16.  GEMM view: D[co][px] = sum_k W[co][k] * X[px][k], k = tap*Cin + c.
+//       A operand = weights (rows = output channels), B operand = activations (columns = pixels),
+//       so a lane's 4 accumulator registers are 4 consecutive output channels of one pixel.
+//       256 threads = 4 waves, each wave owns WPX pixels x BN channels; per K-step (32 channels of
+//       one tap) the block stages [4*WPX][32] activations + [BN][32] weights through registers into
+//       padded LDS rows (80 B: conflict-free ds_read_b128), double-buffered, one barrier per step;
+//       the next step's global loads are issued before the MFMAs of the current one.
+//       Epilogue: + bias (fp32) -> SiLU -> (+ residual) -> fp16, transposed through LDS so that every
+//       pixel row leaves as full 16-byte vectors.  Input, output and residual take a row stride
+//       (ld*) and start at a channel offset, so producers write straight into concat buffers and
+//       consumers read channel slices: no cat / chunk / contiguous copies exist.
+//   k_stem      3x3 stride-2 conv on the planar fp16 tensor K1 writes (Cin = 3), bias + SiLU, NHWC out.
+//   k_maxpool5  5x5 stride-1 max pool on a channel slice (SPPF), NHWC.
+//   k_upsample2 nearest 2x upsample into a channel slice, NHWC.
+//   k_head      DFL expectation + dist2bbox + sigmoid -> [B, 4+nc, A] (anchor axis contiguous).
+//
+// Numerics: fp16 operands, fp32 accumulation and epilogue, one rounding to fp16 per layer output
+// (PyTorch rounds after conv, after bias and after SiLU); the engine is therefore checked against the
+// torch module within an fp16 tolerance, never bit-for-bit.
+#include <hip/hip_fp16.h>
+
+#include "rva_internal.h"
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+struct ConvArgs {
+    const __half *in; int ldi;
+    const __half *w;          // [CoutPad][taps][Cin]
+    const float *bias;        // [CoutPad]
+    __half *out; int ldo;
+    const __half *res; int ldr;
+    int H, W, Cin, CinPad, Ho, Wo, Cout, stride, M, act, n_tiles, m_tiles;   // CinPad = Cin rounded up to 32 (weight rows are zero-padded)
+};
+
+constexpr int LDSROW = 40;  // halfs per staged row: 32 data + 8 pad (80 B) -> conflict-free b128 reads
+
+__device__ __forceinline__ float silu_f(float v) { return __fdividef(v, 1.0f + __expf(-v)); }
+
+template <int BN, int WPX, int KS>
+__global__ void __launch_bounds__(256) k_conv_mfma(ConvArgs a)
+{
+    constexpr int BM = 4 * WPX;
+    constexpr int NA = WPX / 16;   // activation 16-byte chunks per thread per step
+    constexpr int NW = BN / 64;    // weight chunks per thread per step
+    constexpr int TAPS = KS * KS;
+    constexpr int PAD = KS / 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __half *actT = (__half *)smem;                         // [2][BM][LDSROW]
+    __half *wT = actT + 2 * BM * LDSROW;                   // [2][BN][LDSROW]
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // XCD-aware tile order: blocks id and id+8 share an XCD (round-robin dispatch), so the n-tiles of
+    // one m-tile are issued 8 apart and re-read their activations from the same L2 (speed only).
+    int m_tile, n_tile;
+    {
+        const int id = blockIdx.x;
+        if (a.n_tiles > 1 && (a.m_tiles & 7) == 0) {
+            const int xcd = id & 7, slot = id >> 3;
+            n_tile = slot % a.n_tiles;
+            m_tile = (slot / a.n_tiles) * 8 + xcd;
+        } else {
+            n_tile = id % a.n_tiles;
+            m_tile = id / a.n_tiles;
+        }
+    }
+    const int m0 = m_tile * BM, n0 = n_tile * BN;
+    const int HoWo = a.Ho * a.Wo;
+
+    // per-thread source rows (fixed across K-steps)
+    int pix0[NA], iy0[NA], ix0[NA];
+    const int part = tid & 3;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int m = m0 + (tid >> 2) + 64 * i;
+        if (m < a.M) {
+            const int b = m / HoWo, rem = m - b * HoWo;
+            const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+            iy0[i] = oy * a.stride - PAD;
+            ix0[i] = ox * a.stride - PAD;
+            pix0[i] = (b * a.H + iy0[i]) * a.W + ix0[i];
+        } else {
+            iy0[i] = -100000; ix0[i] = -100000; pix0[i] = 0;
+        }
+    }
+    const int cpt = a.CinPad >> 5;       // 32-channel chunks per tap
+    const int nsteps = TAPS * cpt;
+    const size_t wrow = (size_t)TAPS * a.CinPad;
+
+    uint4 ra[NA], rw[NW];
+    auto gload = [&](int tap, int cc) {
+        const int dy = KS == 1 ? 0 : tap / KS, dx = KS == 1 ? 0 : tap - dy * KS;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int iy = iy0[i] + dy, ix = ix0[i] + dx;
+            const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W && (cc << 5) + part * 8 < a.Cin;
+            ra[i] = make_uint4(0, 0, 0, 0);
+            if (ok) {
+                const __half *p = a.in + (size_t)(pix0[i] + dy * a.W + dx) * a.ldi + (cc << 5) + part * 8;
+                ra[i] = *reinterpret_cast<const uint4 *>(p);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int co = n0 + (tid >> 2) + 64 * i;
+            const __half *p = a.w + (size_t)co * wrow + (size_t)tap * a.CinPad + (cc << 5) + part * 8;
+            rw[i] = *reinterpret_cast<const uint4 *>(p);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+            *reinterpret_cast<uint4 *>(actT + ((size_t)buf * BM + (tid >> 2) + 64 * i) * LDSROW + part * 8) = ra[i];
+#pragma unroll
+        for (int i = 0; i < NW; ++i)
+            *reinterpret_cast<uint4 *>(wT + ((size_t)buf * BN + (tid >> 2) + 64 * i) * LDSROW + part * 8) = rw[i];
+    };
+
+    f4 acc[BN / 16][WPX / 16];
+#pragma unroll
+    for (int i = 0; i < BN / 16; ++i)
+#pragma unroll
+        for (int j = 0; j < WPX / 16; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+    int tap = 0, cc = 0;
+    gload(0, 0);
+    lstore(0);
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+        const int buf = s & 1;
+        int ntap = tap, ncc = cc + 1;
+        if (ncc == cpt) { ncc = 0; ++ntap; }
+        const bool more = s + 1 < nsteps;
+        if (more) gload(ntap, ncc);                      // in flight under the MFMAs below
+        const __half *ab = actT + ((size_t)buf * BM + wv * WPX + (lane & 15)) * LDSROW + (lane >> 4) * 8;
+        const __half *wb = wT + ((size_t)buf * BN + (lane & 15)) * LDSROW + (lane >> 4) * 8;
+        h8 bf[WPX / 16];
+#pragma unroll
+        for (int j = 0; j < WPX / 16; ++j) bf[j] = *reinterpret_cast<const h8 *>(ab + j * 16 * LDSROW);
+#pragma unroll
+        for (int i = 0; i < BN / 16; ++i) {
+            const h8 af = *reinterpret_cast<const h8 *>(wb + i * 16 * LDSROW);
+#pragma unroll
+            for (int j = 0; j < WPX / 16; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) lstore(buf ^ 1);
+        __syncthreads();
+        tap = ntap; cc = ncc;
+    }
+
+    // epilogue: bias + SiLU in fp32, transpose through LDS, full-vector stores (+ residual)
+    constexpr int SROW = BN + 8;                          // halfs per staged pixel row
+    __half *stage = (__half *)smem;                       // [BM][SROW], reuses the operand buffers
+#pragma unroll
+    for (int i = 0; i < BN / 16; ++i) {
+        const int co = 16 * i + (lane >> 4) * 4;
+        const float4 bv = *reinterpret_cast<const float4 *>(a.bias + n0 + co);
+#pragma unroll
+        for (int j = 0; j < WPX / 16; ++j) {
+            float v0 = acc[i][j][0] + bv.x, v1 = acc[i][j][1] + bv.y, v2 = acc[i][j][2] + bv.z, v3 = acc[i][j][3] + bv.w;
+            if (a.act) { v0 = silu_f(v0); v1 = silu_f(v1); v2 = silu_f(v2); v3 = silu_f(v3); }
+            const int px = wv * WPX + 16 * j + (lane & 15);
+            __half2 lo = __floats2half2_rn(v0, v1), hi = __floats2half2_rn(v2, v3);
+            uint2 pk;
+            pk.x = *reinterpret_cast<uint32_t *>(&lo);
+            pk.y = *reinterpret_cast<uint32_t *>(&hi);
+            *reinterpret_cast<uint2 *>(stage + (size_t)px * SROW + co) = pk;
+        }
+    }
+    __syncthreads();
+    constexpr int CPR = BN / 8;                           // 16-byte chunks per pixel row
+#pragma unroll 4
+    for (int q = tid; q < BM * CPR; q += 256) {
+        const int row = q / CPR, pc = q - row * CPR;
+        const int m = m0 + row, co = n0 + pc * 8;
+        if (m < a.M && co < a.Cout) {
+            uint4 v = *reinterpret_cast<const uint4 *>(stage + (size_t)row * SROW + pc * 8);
+            if (a.res) {
+                const uint4 r = *reinterpret_cast<const uint4 *>(a.res + (size_t)m * a.ldr + co);
+                __half2 *vh = reinterpret_cast<__half2 *>(&v);
+                const __half2 *rh = reinterpret_cast<const __half2 *>(&r);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float2 x = __half22float2(vh[t]), y = __half22float2(rh[t]);
+                    vh[t] = __floats2half2_rn(x.x + y.x, x.y + y.y);
+                }
+            }
+            *reinterpret_cast<uint4 *>(a.out + (size_t)m * a.ldo + co) = v;
+        }
+    }
+}
+
+template <int BN, int WPX, int KS>
+constexpr size_t conv_smem()
+{
+    constexpr size_t op = (size_t)2 * (4 * WPX + BN) * LDSROW * 2;
+    constexpr size_t st = (size_t)4 * WPX * (BN + 8) * 2;
+    return op > st ? op : st;
+}
+
+template <int BN, int WPX, int KS>
+hipError_t launch_conv(const ConvArgs &a, hipStream_t s)
+{
+    constexpr size_t smem = conv_smem<BN, WPX, KS>();
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_conv_mfma<BN, WPX, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    k_conv_mfma<BN, WPX, KS><<<a.m_tiles * a.n_tiles, 256, smem, s>>>(a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Stem: 3x3 stride-2 pad-1 conv on planar [B,3,H,W] fp16 (what K1 writes), Cout <= 64, NHWC out.
+struct StemArgs {
+    const __half *in; const float *w; const float *bias; __half *out;   // w: [Cout][27] (c, ky, kx)
+    int B, H, W, Ho, Wo, Cout, ldo;
+};
+
+__global__ void __launch_bounds__(256) k_stem(StemArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *sw = (float *)smem;                      // [Cout][28]
+    for (int i = threadIdx.x; i < a.Cout * 27; i += 256) sw[(i / 27) * 28 + i % 27] = a.w[i];
+    for (int i = threadIdx.x; i < a.Cout; i += 256) sw[i * 28 + 27] = a.bias[i];
+    __syncthreads();
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    const int M = a.B * a.Ho * a.Wo;
+    if (m >= M) return;
+    const int b = m / (a.Ho * a.Wo), rem = m - b * a.Ho * a.Wo, oy = rem / a.Wo, ox = rem - oy * a.Wo;
+    float x[27];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int iy = oy * 2 - 1 + ky, ix = ox * 2 - 1 + kx;
+                float v = 0.f;
+                if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+                    v = __half2float(a.in[((size_t)(b * 3 + c) * a.H + iy) * a.W + ix]);
+                x[c * 9 + ky * 3 + kx] = v;
+            }
+    __half *o = a.out + (size_t)m * a.ldo;
+    for (int co = 0; co < a.Cout; co += 8) {
+        alignas(16) __half r[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float *wr = sw + (co + u) * 28;
+            float s = wr[27];
+#pragma unroll
+            for (int k = 0; k < 27; ++k) s = fmaf(wr[k], x[k], s);
+            r[u] = __float2half_rn(silu_f(s));
+        }
+        *reinterpret_cast<uint4 *>(o + co) = *reinterpret_cast<const uint4 *>(r);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 5x5 stride-1 pad-2 max pool over a channel slice (C % 8 == 0): thread = (pixel, 8 channels)
+__global__ void __launch_bounds__(256) k_maxpool5(const __half *in, int ldi, __half *out, int ldo, int B, int H, int W, int C)
+{
+    const int cg = C >> 3;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)B * H * W * cg) return;
+    const int g = (int)(idx % cg);
+    const long pix = idx / cg;
+    const int x = (int)(pix % W), y = (int)((pix / W) % H), b = (int)(pix / ((long)W * H));
+    h8 mx;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) mx[t] = (_Float16)-65504.f;
+    for (int dy = -2; dy <= 2; ++dy) {
+        const int yy = y + dy;
+        if ((unsigned)yy >= (unsigned)H) continue;
+        for (int dx = -2; dx <= 2; ++dx) {
+            const int xx = x + dx;
+            if ((unsigned)xx >= (unsigned)W) continue;
+            const h8 v = *reinterpret_cast<const h8 *>(in + ((size_t)(b * H + yy) * W + xx) * ldi + g * 8);
+            mx = __builtin_elementwise_max(mx, v);
+        }
+    }
+    *reinterpret_cast<h8 *>(out + (size_t)pix * ldo + g * 8) = mx;
+}
+
+// nearest 2x upsample: out pixel (y, x) <- in pixel (y/2, x/2); thread = (out pixel, 8 channels)
+__global__ void __launch_bounds__(256) k_upsample2(const __half *in, int ldi, __half *out, int ldo, int B, int H, int W, int C)
+{
+    const int cg = C >> 3, Ho = H * 2, Wo = W * 2;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)B * Ho * Wo * cg) return;
+    const int g = (int)(idx % cg);
+    const long pix = idx / cg;
+    const int x = (int)(pix % Wo), y = (int)((pix / Wo) % Ho), b = (int)(pix / ((long)Wo * Ho));
+    const uint4 v = *reinterpret_cast<const uint4 *>(in + ((size_t)(b * H + (y >> 1)) * W + (x >> 1)) * ldi + g * 8);
+    *reinterpret_cast<uint4 *>(out + (size_t)pix * ldo + g * 8) = v;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Detect head: box logits [B, hw, 4*16] + class logits [B, hw, nc] of one level ->
+// out[B, 4+nc, A] at anchor offset a0 (xywh * stride, sigmoid scores).  Thread = anchor.
+struct HeadArgs {
+    const __half *box; int ldb; const __half *cls; int ldc; __half *out;
+    int B, h, w, nc, A, a0; float stride;
+};
+
+__global__ void __launch_bounds__(256) k_head(HeadArgs a)
+{
+    const int hw = a.h * a.w;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (i >= hw) return;
+    const size_t pix = (size_t)b * hw + i;
+    const __half *bp = a.box + pix * a.ldb;
+    float d[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        float v[16], mx = -1e30f;
+        const uint4 q0 = *reinterpret_cast<const uint4 *>(bp + s * 16), q1 = *reinterpret_cast<const uint4 *>(bp + s * 16 + 8);
+        const __half2 *h0 = reinterpret_cast<const __half2 *>(&q0), *h1 = reinterpret_cast<const __half2 *>(&q1);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float2 f = __half22float2(h0[t]); v[2 * t] = f.x; v[2 * t + 1] = f.y;
+            f = __half22float2(h1[t]); v[8 + 2 * t] = f.x; v[9 + 2 * t] = f.y;
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) mx = fmaxf(mx, v[t]);
+        float se = 0.f, sw = 0.f;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) { const float e = __expf(v[t] - mx); se += e; sw += e * (float)t; }
+        d[s] = sw / se;                                  // DFL expectation
+    }
+    const float ax = (float)(i % a.w) + 0.5f, ay = (float)(i / a.w) + 0.5f;
+    const float x1 = ax - d[0], y1 = ay - d[1], x2 = ax + d[2], y2 = ay + d[3];
+    __half *o = a.out + (size_t)b * (4 + a.nc) * a.A + a.a0 + i;
+    o[0] = __float2half_rn((x1 + x2) * 0.5f * a.stride);
+    o[(size_t)a.A] = __float2half_rn((y1 + y2) * 0.5f * a.stride);
+    o[(size_t)2 * a.A] = __float2half_rn((x2 - x1) * a.stride);
+    o[(size_t)3 * a.A] = __float2half_rn((y2 - y1) * a.stride);
+    const __half *cp = a.cls + pix * a.ldc;
+    for (int c = 0; c < a.nc; c += 8) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(cp + c);
+        const __half2 *hq = reinterpret_cast<const __half2 *>(&q);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float2 f = __half22float2(hq[t]);
+            o[(size_t)(4 + c + 2 * t) * a.A] = __float2half_rn(1.0f / (1.0f + __expf(-f.x)));
+            o[(size_t)(5 + c + 2 * t) * a.A] = __float2half_rn(1.0f / (1.0f + __expf(-f.y)));
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int rva_conv2d_nhwc_f16(rva_ctx *ctx, const void *in, int ldi, const void *weights, const float *bias, void *out,
+                        int ldo, const void *residual, int ldr, int batch, int H, int W, int Cin, int Cout, int ksize,
+                        int stride, int act, rva_stream_t stream_)
+{
+    if (!ctx) return RVA_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream_;
+    if (!in || !weights || !bias || !out || batch <= 0 || H <= 0 || W <= 0 || (ksize != 1 && ksize != 3) ||
+        (stride != 1 && stride != 2) || Cin % 8 || Cout % 8 || ldi % 8 || ldo % 8 || (residual && ldr % 8) ||
+        ((uintptr_t)in | (uintptr_t)out | (uintptr_t)weights | (uintptr_t)residual) % 16)
+        return rva_fail(ctx, RVA_ERR_ARG, "rva_conv2d_nhwc_f16: unsupported shape/alignment (Cin%%8, Cout%%8, ld%%8, 16-byte pointers)");
+    ConvArgs a{};
+    a.in = (const __half *)in; a.ldi = ldi; a.w = (const __half *)weights; a.bias = bias;
+    a.out = (__half *)out; a.ldo = ldo; a.res = (const __half *)residual; a.ldr = ldr;
+    a.H = H; a.W = W; a.Cin = Cin; a.CinPad = rva_ceil_div(Cin, 32) * 32; a.Cout = Cout; a.stride = stride; a.act = act;
+    const int pad = ksize / 2;
+    a.Ho = (H + 2 * pad - ksize) / stride + 1;
+    a.Wo = (W + 2 * pad - ksize) / stride + 1;
+    a.M = batch * a.Ho * a.Wo;
+    // tile choice: weights are padded to a multiple of 64 output channels by the caller (rva_conv_cout_pad)
+    const int cpad = rva_ceil_div(Cout, 64) * 64;
+    const bool bn128 = cpad % 128 == 0;
+    const int BN = bn128 ? 128 : 64;
+    a.n_tiles = cpad / BN;
+    // small problems: 128-pixel tiles keep more CUs busy
+    const bool small = (long)rva_ceil_div(a.M, 256) * a.n_tiles < 512;
+    const int BM = small ? 128 : 256;
+    a.m_tiles = rva_ceil_div(a.M, BM);
+    hipError_t e;
+#define RVA_CONV(BN_, WPX_)                                                  \
+    (ksize == 1 ? launch_conv<BN_, WPX_, 1>(a, s) : launch_conv<BN_, WPX_, 3>(a, s))
+    if (bn128) e = small ? RVA_CONV(128, 32) : RVA_CONV(128, 64);
+    else e = small ? RVA_CONV(64, 32) : RVA_CONV(64, 64);
+#undef RVA_CONV
+    (void)BN;
+    if (e != hipSuccess) return rva_fail(ctx, RVA_ERR_HIP, "conv launch failed: %s", hipGetErrorString(e));
+    return RVA_OK;
+}
+
+int rva_conv_cout_pad(int Cout) { return rva_ceil_div(Cout, 64) * 64; }
+
+int rva_stem_conv_f16(rva_ctx *ctx, const void *in_planar, const float *weights, const float *bias, void *out, int ldo,
+                      int batch, int H, int W, int Cout, rva_stream_t stream_)
+{
+    if (!ctx || !in_planar || !weights || !bias || !out || Cout % 8 || Cout > 64 || ldo % 8)
+        return rva_fail(ctx, RVA_ERR_ARG, "rva_stem_conv_f16: bad argument");
+    StemArgs a{(const __half *)in_planar, weights, bias, (__half *)out, batch, H, W, (H - 1) / 2 + 1, (W - 1) / 2 + 1, Cout, ldo};
+    const int M = batch * a.Ho * a.Wo;
+    k_stem<<<rva_ceil_div(M, 256), 256, (size_t)Cout * 28 * 4, (hipStream_t)stream_>>>(a);
+    RVA_HIP(ctx, hipGetLastError());
+    return RVA_OK;
+}
+
+int rva_maxpool5_nhwc_f16(rva_ctx *ctx, const void *in, int ldi, void *out, int ldo, int batch, int H, int W, int C,
+                          rva_stream_t stream_)
+{
+    if (!ctx || !in || !out || C % 8 || ldi % 8 || ldo % 8) return rva_fail(ctx, RVA_ERR_ARG, "rva_maxpool5_nhwc_f16: bad argument");
+    const long n = (long)batch * H * W * (C / 8);
+    k_maxpool5<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream_>>>((const __half *)in, ldi, (__half *)out, ldo, batch, H, W, C);
+    RVA_HIP(ctx, hipGetLastError());
+    return RVA_OK;
+}
+
+int rva_upsample2x_nhwc_f16(rva_ctx *ctx, const void *in, int ldi, void *out, int ldo, int batch, int H, int W, int C,
+                            rva_stream_t stream_)
+{
+    if (!ctx || !in || !out || C % 8 || ldi % 8 || ldo % 8) return rva_fail(ctx, RVA_ERR_ARG, "rva_upsample2x_nhwc_f16: bad argument");
+    const long n = (long)batch * H * 2 * W * 2 * (C / 8);
+    k_upsample2<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream_>>>((const __half *)in, ldi, (__half *)out, ldo, batch, H, W, C);
+    RVA_HIP(ctx, hipGetLastError());
+    return RVA_OK;
+}
+
+int rva_yolo_head_f16(rva_ctx *ctx, const void *box_logits, int ldb, const void *cls_logits, int ldc, void *out, int batch,
+                      int h, int w, int nc, int anchors_total, int anchor_offset, float stride, rva_stream_t stream_)
+{
+    if (!ctx || !box_logits || !cls_logits || !out || nc % 8 || ldb % 8 || ldc % 8)
+        return rva_fail(ctx, RVA_ERR_ARG, "rva_yolo_head_f16: bad argument");
+    HeadArgs a{(const __half *)box_logits, ldb, (const __half *)cls_logits, ldc, (__half *)out, batch, h, w, nc,
+               anchors_total, anchor_offset, stride};
+    dim3 g(rva_ceil_div(h * w, 256), batch);
+    k_head<<<g, 256, 0, (hipStream_t)stream_>>>(a);
+    RVA_HIP(ctx, hipGetLastError());
+    return RVA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,223 @@
+"""Fused YOLOv8 execution plan on the librva detector primitives.
+
+Takes the seeded/loaded ``yolov8.YoloV8`` module (BatchNorm folded) as the weight container and
+runs the same graph as a static list of HIP launches on NHWC fp16 buffers:
+
+  * every Conv-BN-SiLU is ONE launch (MFMA implicit GEMM, bias + SiLU [+ residual] epilogue);
+  * ``torch.cat`` / ``chunk`` never materialise: producers write channel slices of pre-allocated
+    concat buffers and consumers read slices through a row stride (C2f, SPPF, FPN joins);
+  * SPPF max-pools, FPN upsampling and the DFL/sigmoid decode are small NHWC kernels;
+  * output is the same ``[B, 4+nc, A]`` fp16 tensor the torch module returns, so everything
+    downstream (K2/K3/K4) and every parity test is unchanged.
+
+The plan has no host synchronisation and allocates nothing after construction, so a whole tick can
+be captured into a hipGraph.  Self-parity against the torch module is a test (fp16 tolerance).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, Dict, List, Optional, Tuple
+
+import torch
+
+from . import _native as N
+from . import ops
+from .yolov8 import Bottleneck, C2f, ConvBnAct, SPPF, YoloV8
+
+
+def _p(t: torch.Tensor) -> C.c_void_p:
+    return C.c_void_p(t.data_ptr())
+
+
+class _View:
+    """A channel slice of an NHWC buffer: (tensor [M, ld], channel offset, channels)."""
+
+    __slots__ = ("buf", "off", "ch")
+
+    def __init__(self, buf: torch.Tensor, off: int, ch: int):
+        self.buf, self.off, self.ch = buf, off, ch
+
+    @property
+    def ld(self) -> int:
+        return int(self.buf.shape[-1])
+
+    @property
+    def ptr(self) -> C.c_void_p:
+        return C.c_void_p(self.buf.data_ptr() + 2 * self.off)
+
+    def sub(self, off: int, ch: int) -> "_View":
+        assert off + ch <= self.ch
+        return _View(self.buf, self.off + off, ch)
+
+
+class FusedYoloV8:
+    def __init__(self, net: YoloV8, batch: int, hw: Tuple[int, int] = (640, 640), device: Optional[torch.device] = None,
+                 ctx: Optional[N.Context] = None):
+        self.ctx = ctx or ops.context()
+        self.dev = device or torch.device("cuda", self.ctx.device)
+        self.B, self.H, self.W = batch, hw[0], hw[1]
+        assert hw[0] % 32 == 0 and hw[1] % 32 == 0
+        net = net.fuse()
+        self.nc = net.nc
+        self.L = N.lib()
+        self._keep: List[torch.Tensor] = []
+        self._steps: List[Callable[[C.c_void_p], None]] = []
+        self._build(net)
+
+    # -- weight preparation ---------------------------------------------------------------------------
+    def _conv_params(self, conv: torch.nn.Conv2d):
+        w = conv.weight.detach().float()                      # [Cout, Cin, k, k]
+        cout, cin, k, _ = w.shape
+        cpad = self.L.rva_conv_cout_pad(cout)
+        cinp = (cin + 31) // 32 * 32
+        wp = torch.zeros((cpad, k * k, cinp), dtype=torch.float16)
+        wp[:cout, :, :cin] = w.permute(0, 2, 3, 1).reshape(cout, k * k, cin).half()
+        bp = torch.zeros((cpad,), dtype=torch.float32)
+        if conv.bias is not None:
+            bp[:cout] = conv.bias.detach().float()
+        wp, bp = wp.to(self.dev).contiguous(), bp.to(self.dev).contiguous()
+        self._keep += [wp, bp]
+        return wp, bp, cin, cout, k, conv.stride[0]
+
+    def _buf(self, m: int, ch: int) -> torch.Tensor:
+        t = torch.zeros((m, ch), dtype=torch.float16, device=self.dev)
+        self._keep.append(t)
+        return t
+
+    # -- step emitters --------------------------------------------------------------------------------
+    def _conv(self, mod, src: _View, dst: _View, h: int, w: int, res: Optional[_View] = None):
+        conv = mod.conv if isinstance(mod, ConvBnAct) else mod
+        act = 1 if isinstance(mod, ConvBnAct) and mod.act else 0
+        wp, bp, cin, cout, k, stride = self._conv_params(conv)
+        assert cin == src.ch and cout == dst.ch, (cin, src.ch, cout, dst.ch)
+        B, L, ctx = self.B, self.L, self.ctx
+
+        def run(stream, src=src, dst=dst, res=res):
+            rc = L.rva_conv2d_nhwc_f16(ctx.handle, src.ptr, src.ld, _p(wp), _p(bp), dst.ptr, dst.ld,
+                                       res.ptr if res else None, res.ld if res else 0, B, h, w, cin, cout, k, stride, act,
+                                       stream)
+            ctx.check(rc, "rva_conv2d_nhwc_f16")
+        self._steps.append(run)
+        return (h - 1) // stride + 1 if k == 3 else h // stride, (w - 1) // stride + 1 if k == 3 else w // stride
+
+    def _c2f(self, mod: C2f, src: _View, dst: _View, h: int, w: int):
+        c, n = mod.c, len(mod.m)
+        m = self.B * h * w
+        cat = _View(self._buf(m, (2 + n) * c), 0, (2 + n) * c)
+        self._conv(mod.cv1, src, cat.sub(0, 2 * c), h, w)
+        tmp = _View(self._buf(m, c), 0, c)
+        for i, b in enumerate(mod.m):
+            x = cat.sub((1 + i) * c, c)
+            self._conv(b.cv1, x, tmp, h, w)
+            self._conv(b.cv2, tmp, cat.sub((2 + i) * c, c), h, w, res=x if b.add else None)
+        self._conv(mod.cv2, cat, dst, h, w)
+
+    def _sppf(self, mod: SPPF, src: _View, dst: _View, h: int, w: int):
+        c_ = mod.cv1.conv.out_channels
+        m = self.B * h * w
+        cat = _View(self._buf(m, 4 * c_), 0, 4 * c_)
+        self._conv(mod.cv1, src, cat.sub(0, c_), h, w)
+        B, L, ctx = self.B, self.L, self.ctx
+        for i in range(3):
+            s, d = cat.sub(i * c_, c_), cat.sub((i + 1) * c_, c_)
+
+            def run(stream, s=s, d=d):
+                ctx.check(L.rva_maxpool5_nhwc_f16(ctx.handle, s.ptr, s.ld, d.ptr, d.ld, B, h, w, c_, stream), "maxpool5")
+            self._steps.append(run)
+        self._conv(mod.cv2, cat, dst, h, w)
+
+    def _upsample(self, src: _View, dst: _View, h: int, w: int):
+        B, L, ctx = self.B, self.L, self.ctx
+
+        def run(stream):
+            ctx.check(L.rva_upsample2x_nhwc_f16(ctx.handle, src.ptr, src.ld, dst.ptr, dst.ld, B, h, w, src.ch, stream), "upsample")
+        self._steps.append(run)
+
+    # -- the graph ------------------------------------------------------------------------------------
+    def _build(self, net: YoloV8):
+        B, H, W = self.B, self.H, self.W
+        c1 = net.b0.conv.out_channels; c2 = net.b1.conv.out_channels; c3 = net.b3.conv.out_channels
+        c4 = net.b5.conv.out_channels; c5 = net.b7.conv.out_channels
+        h1, w1, h2, w2 = H // 2, W // 2, H // 4, W // 4
+        h3, w3, h4, w4, h5, w5 = H // 8, W // 8, H // 16, W // 16, H // 32, W // 32
+        # stem (planar input from K1)
+        sw = net.b0.conv.weight.detach().float().reshape(c1, 27).contiguous().to(self.dev)
+        sb = net.b0.conv.bias.detach().float().contiguous().to(self.dev)
+        self._keep += [sw, sb]
+        x0 = _View(self._buf(B * h1 * w1, c1), 0, c1)
+        L, ctx = self.L, self.ctx
+        self._in_ptr = None
+
+        def stem(stream):
+            ctx.check(L.rva_stem_conv_f16(ctx.handle, self._in_ptr, _p(sw), _p(sb),
+                                          x0.ptr, x0.ld, B, H, W, c1, stream), "stem")
+        self._steps.append(stem)
+        x1 = _View(self._buf(B * h2 * w2, c2), 0, c2)
+        self._conv(net.b1, x0, x1, h1, w1)
+        x2 = _View(self._buf(B * h2 * w2, c2), 0, c2)
+        self._c2f(net.b2, x1, x2, h2, w2)
+        # concat buffers of the neck: producers write their slice directly
+        cat15 = _View(self._buf(B * h3 * w3, c4 + c3), 0, c4 + c3)     # [up(n4) | p3]
+        cat12 = _View(self._buf(B * h4 * w4, c5 + c4), 0, c5 + c4)     # [up(p5) | p4]
+        cat18 = _View(self._buf(B * h4 * w4, c3 + c4), 0, c3 + c4)     # [h16(n3) | n4]
+        cat21 = _View(self._buf(B * h5 * w5, c4 + c5), 0, c4 + c5)     # [h19(m4) | p5]
+        p3, p4, n4, p5 = cat15.sub(c4, c3), cat12.sub(c5, c4), cat18.sub(c3, c4), cat21.sub(c4, c5)
+        t3 = _View(self._buf(B * h3 * w3, c3), 0, c3)
+        self._conv(net.b3, x2, t3, h2, w2)
+        self._c2f(net.b4, t3, p3, h3, w3)
+        t4 = _View(self._buf(B * h4 * w4, c4), 0, c4)
+        self._conv(net.b5, p3, t4, h3, w3)
+        self._c2f(net.b6, t4, p4, h4, w4)
+        t5 = _View(self._buf(B * h5 * w5, c5), 0, c5)
+        self._conv(net.b7, p4, t5, h4, w4)
+        t5b = _View(self._buf(B * h5 * w5, c5), 0, c5)
+        self._c2f(net.b8, t5, t5b, h5, w5)
+        self._sppf(net.b9, t5b, p5, h5, w5)
+        self._upsample(p5, cat12.sub(0, c5), h5, w5)
+        self._c2f(net.h12, cat12, n4, h4, w4)
+        self._upsample(n4, cat15.sub(0, c4), h4, w4)
+        n3 = _View(self._buf(B * h3 * w3, c3), 0, c3)
+        self._c2f(net.h15, cat15, n3, h3, w3)
+        self._conv(net.h16, n3, cat18.sub(0, c3), h3, w3)
+        m4 = _View(self._buf(B * h4 * w4, c4), 0, c4)
+        self._c2f(net.h18, cat18, m4, h4, w4)
+        self._conv(net.h19, m4, cat21.sub(0, c4), h4, w4)
+        m5 = _View(self._buf(B * h5 * w5, c5), 0, c5)
+        self._c2f(net.h21, cat21, m5, h5, w5)
+        # detect head
+        A = h3 * w3 + h4 * w4 + h5 * w5
+        self.A = A
+        self.out = torch.empty((B, 4 + self.nc, A), dtype=torch.float16, device=self.dev)
+        a0 = 0
+        for lvl, (feat, hh, ww, stride) in enumerate(((n3, h3, w3, 8.0), (m4, h4, w4, 16.0), (m5, h5, w5, 32.0))):
+            box, cls = net.detect.box[lvl], net.detect.cls[lvl]
+            m = B * hh * ww
+            cb = box[0].conv.out_channels
+            cc = cls[0].conv.out_channels
+            b1 = _View(self._buf(m, cb), 0, cb); b2 = _View(self._buf(m, cb), 0, cb)
+            bo = _View(self._buf(m, 64), 0, 64)
+            k1 = _View(self._buf(m, cc), 0, cc); k2 = _View(self._buf(m, cc), 0, cc)
+            ko = _View(self._buf(m, self.nc), 0, self.nc)
+            self._conv(box[0], feat, b1, hh, ww); self._conv(box[1], b1, b2, hh, ww); self._conv(box[2], b2, bo, hh, ww)
+            self._conv(cls[0], feat, k1, hh, ww); self._conv(cls[1], k1, k2, hh, ww); self._conv(cls[2], k2, ko, hh, ww)
+            B_, out, nc = B, self.out, self.nc
+
+            def head(stream, bo=bo, ko=ko, hh=hh, ww=ww, a0=a0, stride=stride):
+                ctx.check(L.rva_yolo_head_f16(ctx.handle, bo.ptr, bo.ld, ko.ptr, ko.ld, _p(out), B_, hh, ww, nc, A, a0,
+                                              C.c_float(stride), stream), "yolo_head")
+            self._steps.append(head)
+            a0 += hh * ww
+
+    # -- run ------------------------------------------------------------------------------------------
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        """``x``: fp16 planar ``[B,3,H,W]`` contiguous (what K1 writes).  Returns ``[B, 4+nc, A]`` fp16."""
+        assert x.is_cuda and x.dtype == torch.float16 and x.is_contiguous() and tuple(x.shape) == (self.B, 3, self.H, self.W)
+        self._in_ptr = C.c_void_p(x.data_ptr())
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for step in self._steps:
+            step(stream)
+        return self.out
+
+    @property
+    def n_launches(self) -> int:
+        return len(self._steps)

@@ -1,0 +1,100 @@
+"""Fused detector primitives and the fused YOLOv8 plan against the torch module (self-parity, fp16
+tolerance: the plan rounds once per layer, torch rounds after conv, bias and SiLU)."""
+import copy
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from realtime_video_analytics_32streams_amd import _native as N
+from realtime_video_analytics_32streams_amd import ops
+from realtime_video_analytics_32streams_amd.engine import FusedYoloV8
+from realtime_video_analytics_32streams_amd.yolov8 import build_detector_net
+
+pytestmark = pytest.mark.gpu
+
+
+def _conv_ref(x_nhwc, w, b, k, stride, act, res=None):
+    """fp32 reference on the fp16-rounded operands: x [B,H,W,Cin], w [Cout,Cin,k,k]."""
+    y = F.conv2d(x_nhwc.float().permute(0, 3, 1, 2), w.float(), b.float(), stride=stride, padding=k // 2)
+    if act:
+        y = F.silu(y)
+    y = y.permute(0, 2, 3, 1)
+    if res is not None:
+        y = y + res.float()
+    return y
+
+
+@pytest.mark.parametrize("shape", [
+    # B, H, W, Cin, Cout, k, stride, act, residual, in_extra, out_extra (channel-slice strides)
+    (2, 20, 20, 32, 64, 1, 1, 1, False, 0, 0),
+    (2, 20, 20, 64, 64, 3, 1, 1, True, 32, 64),
+    (3, 17, 23, 32, 128, 3, 2, 1, False, 8, 0),
+    (1, 40, 40, 128, 128, 3, 1, 1, True, 0, 128),
+    (2, 16, 16, 48, 96, 3, 1, 1, False, 16, 8),       # Cin not a multiple of 32 (YOLOv8m widths)
+    (2, 16, 16, 16, 32, 1, 1, 0, False, 0, 0),        # Cin = 16 (YOLOv8n), no activation
+    (2, 20, 20, 128, 80, 1, 1, 0, False, 0, 0),       # class head: Cout = 80
+    (32, 80, 80, 64, 64, 3, 1, 1, True, 64, 64),      # full-size P3 bottleneck conv (BM = 256 path)
+    (4, 20, 20, 256, 512, 3, 1, 1, False, 0, 0),      # multi n-tile + XCD-aware order
+    (1, 7, 9, 512, 256, 1, 1, 1, False, 0, 0),        # M tail (63 pixels)
+])
+def test_conv_primitive_matches_fp32_reference(shape):
+    B, H, W, Cin, Cout, k, stride, act, use_res, ie, oe = shape
+    g = torch.Generator().manual_seed(hash(shape) & 0xffff)
+    x_full = (torch.randn((B, H, W, Cin + ie), generator=g) * 0.5).half().cuda()
+    x = x_full[..., ie:]                                   # channel slice with row stride Cin+ie
+    w = (torch.randn((Cout, Cin, k, k), generator=g) / (Cin * k * k) ** 0.5).half()
+    b = torch.randn((Cout,), generator=g) * 0.1
+    Ho, Wo = ((H - 1) // stride + 1, (W - 1) // stride + 1) if k == 3 else (H // stride, W // stride)
+    out_full = torch.full((B, Ho, Wo, Cout + oe), 7.0, dtype=torch.float16, device="cuda")
+    res = (torch.randn((B, Ho, Wo, Cout), generator=g) * 0.5).half().cuda() if use_res else None
+    L, ctx = N.lib(), ops.context()
+    cpad, cinp = L.rva_conv_cout_pad(Cout), (Cin + 31) // 32 * 32
+    wp = torch.zeros((cpad, k * k, cinp), dtype=torch.float16)
+    wp[:Cout, :, :Cin] = w.permute(0, 2, 3, 1).reshape(Cout, k * k, Cin)
+    bp = torch.zeros(cpad); bp[:Cout] = b
+    wp, bp = wp.cuda(), bp.cuda()
+    rc = L.rva_conv2d_nhwc_f16(ctx.handle, C.c_void_p(x.data_ptr()), Cin + ie, C.c_void_p(wp.data_ptr()), C.c_void_p(bp.data_ptr()),
+                               C.c_void_p(out_full.data_ptr() + 2 * oe), Cout + oe, C.c_void_p(res.data_ptr()) if use_res else None,
+                               Cout, B, H, W, Cin, Cout, k, stride, act, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    ctx.check(rc)
+    torch.cuda.synchronize()
+    want = _conv_ref(x, w.cuda(), b.cuda(), k, stride, act, res)
+    got = out_full[..., oe:].float()
+    err = (got - want).abs().max().item()
+    assert err < 2e-2 + 2e-3 * want.abs().max().item(), err
+    if oe:
+        assert torch.all(out_full[..., :oe] == 7.0)        # the neighbouring slice is untouched
+
+
+def test_pool_upsample_head_primitives():
+    L, ctx = N.lib(), ops.context()
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    x = torch.randn((2, 20, 20, 64 + 32)).half().cuda()
+    out = torch.zeros((2, 20, 20, 32), dtype=torch.float16, device="cuda")
+    ctx.check(L.rva_maxpool5_nhwc_f16(ctx.handle, C.c_void_p(x.data_ptr() + 2 * 64), 96, C.c_void_p(out.data_ptr()), 32, 2, 20, 20, 32, s))
+    want = F.max_pool2d(x[..., 64:].permute(0, 3, 1, 2).float(), 5, 1, 2).permute(0, 2, 3, 1)
+    assert torch.equal(out.float(), want)
+    up = torch.zeros((2, 40, 40, 32), dtype=torch.float16, device="cuda")
+    ctx.check(L.rva_upsample2x_nhwc_f16(ctx.handle, C.c_void_p(out.data_ptr()), 32, C.c_void_p(up.data_ptr()), 32, 2, 20, 20, 32, s))
+    assert torch.equal(up, out.repeat_interleave(2, 1).repeat_interleave(2, 2))
+
+
+@pytest.mark.parametrize("scale,batch", [("s", 2), ("n", 2), ("m", 1)])
+def test_fused_plan_matches_torch_module(scale, batch):
+    net = build_detector_net(scale, seed=0)
+    ref = copy.deepcopy(net).fuse().float().cuda()
+    eng = FusedYoloV8(copy.deepcopy(net), batch)
+    x = torch.rand((batch, 3, 640, 640), device="cuda").half()
+    with torch.inference_mode():
+        want = ref(x.float())
+        got = eng(x).float()
+    torch.cuda.synchronize()
+    assert got.shape == want.shape == (batch, 84, 8400)
+    assert torch.isfinite(got).all()
+    assert (got[:, :4] - want[:, :4]).abs().max() < 2.0          # pixels
+    assert (got[:, 4:] - want[:, 4:]).abs().max() < 2e-2         # class probabilities
+    # tighter in the mean: the plan is not systematically off
+    assert (got[:, :4] - want[:, :4]).abs().mean() < 0.2
