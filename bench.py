@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames in the CPU-baseline sample (0 = auto)")
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark = True")
+    ap.add_argument("--engine", default="fused", choices=["fused", "torch"],
+                    help="detector network: librva fused plan (MFMA conv + fused epilogues) or torch/MIOpen")
     ap.add_argument("--depth", type=int, default=2, choices=[1, 2],
                     help="ticks in flight: 2 = tick k+1 is enqueued before tick k's tracks are consumed (GPU never idles "
                          "on host work); 1 = strictly synchronous ticks (lowest latency)")
@@ -90,12 +92,13 @@ def main():
     net_cpu = build_detector_net(args.model, seed=0)
     macs = count_macs(net_cpu)
     import copy
-    det = HipYoloDetector(dcfg, net=copy.deepcopy(net_cpu), device=local)
+    det = HipYoloDetector(dcfg, net=copy.deepcopy(net_cpu), device=local, engine=args.engine)
     # synthetic weights: shift the class biases so a realistic number of anchors clears the threshold
     with torch.inference_mode():
         sample, _ = ops.preprocess_nv12([src._ring[0] for src in sources[:8]], (640, 640), half=True)
     shifts = calibrate_detection_density(det.net, sample.contiguous(memory_format=torch.channels_last), args.conf,
                                          args.target_dets)
+    det.invalidate_engine()
     tcfg = TrackerConfig(max_age=30, max_iou_distance=0.5, min_hits=1)
     trk = IouTracker(tcfg, max_streams=S, capacity=1024, device=local)
     id_sync = rdist.IdSync(S, dev) if world > 1 else None
@@ -191,7 +194,7 @@ def main():
                                if world > 1 else
                                f"{S}x{args.width}x{args.height} NV12 streams resident in HBM, YOLOv8{args.model} fp16 "
                                f"batch={S}, IoU tracker (BASELINE configs[2])",
-                   "streams_per_gpu": S, "detector": f"yolov8{args.model}", "input": [640, 640],
+                   "streams_per_gpu": S, "detector": f"yolov8{args.model}", "detector_engine": args.engine, "input": [640, 640],
                    "weights": "seeded random, class biases calibrated to ~%d candidates/frame" % args.target_dets,
                    "conf": args.conf, "iou": args.iou, "tracker": {"max_age": 30, "max_iou_distance": 0.5, "min_hits": 1},
                    "decode": "not measured: " + rocdecode_status()},

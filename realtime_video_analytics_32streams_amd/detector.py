@@ -89,8 +89,14 @@ class HipYoloDetector(BaseDetector):
     """
 
     def __init__(self, config: DetectorConfig, infer_fn=None, net: Optional[torch.nn.Module] = None,
-                 seed: int = 0, device: Optional[int] = None):
+                 seed: int = 0, device: Optional[int] = None, engine: str = "fused"):
+        """``engine``: ``"fused"`` runs the network as the librva plan (one MFMA launch per layer, fp16 only);
+        ``"torch"`` runs the torch module through MIOpen (also the fp32 path)."""
         super().__init__(config)
+        if engine not in ("fused", "torch"):
+            raise ValueError("engine must be 'fused' or 'torch'")
+        self.engine = engine
+        self._plans = {}
         self.ctx = ops.context(device)            # raises RuntimeError when no HIP device (no CPU fallback)
         self.device = torch.device("cuda", self.ctx.device)
         if config.input_size:
@@ -131,9 +137,20 @@ class HipYoloDetector(BaseDetector):
             dev.append(t.to(self.device, non_blocking=True).contiguous())
         return ops.preprocess_bgr(dev, self.input_hw, self.half, out=self._in, ctx=self.ctx)
 
+    def invalidate_engine(self) -> None:
+        """Drop cached fused plans (call after editing ``self.net``'s weights)."""
+        self._plans.clear()
+
     def _infer(self, tensor: torch.Tensor) -> torch.Tensor:
         if self._infer_fn is not None:
             return self._infer_fn(tensor)
+        if self.engine == "fused" and self.half and tensor.dtype == torch.float16:
+            key = (int(tensor.shape[0]), int(tensor.shape[2]), int(tensor.shape[3]))
+            plan = self._plans.get(key)
+            if plan is None:
+                from .engine import FusedYoloV8
+                plan = self._plans[key] = FusedYoloV8(self.net, key[0], key[1:], device=self.device, ctx=self.ctx)
+            return plan(tensor.contiguous())
         return self.net(tensor.contiguous(memory_format=torch.channels_last))
 
     def _postprocess_device(self, raw: torch.Tensor, metas: Sequence[N.Letterbox]) -> ops.PostBuffers:

@@ -90,6 +90,7 @@ def _make_pipe(n_streams, scale="n", seed=0):
     with torch.inference_mode():
         sample, _ = ops.preprocess_nv12([s._ring[0] for s in srcs], (640, 640), half=True)
     calibrate_detection_density(det.net, sample.contiguous(memory_format=torch.channels_last), 0.25, 80)
+    det.invalidate_engine()
     trk = IouTracker(TrackerConfig(max_age=5, max_iou_distance=0.5, min_hits=1), max_streams=n_streams, capacity=512)
     return streams, det, trk, srcs
 
