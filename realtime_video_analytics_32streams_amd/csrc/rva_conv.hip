@@ -222,6 +222,196 @@ hipError_t launch_conv(const ConvArgs &a, hipStream_t s)
     return hipGetLastError();
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// 3x3 stride-1 convolution, halo-strip variant.  A block owns 4*WPX consecutive output pixels (raster
+// order) of ONE image and all BN output channels.  Per 32-channel chunk the input rows the strip
+// touches (+1 halo row above/below, +1 zero column left/right) are staged ONCE in LDS and all nine taps
+// read their B fragments from that tile at a per-tap offset -- 9x fewer L2->LDS bytes than re-gathering
+// per tap, and the next chunk's loads fly under nine MFMA steps.  Weights stream per (chunk, tap) through
+// a double-buffered [BN][32] LDS tile, one step ahead.
+struct StripArgs {
+    const __half *in; int ldi;
+    const __half *w; const float *bias;
+    __half *out; int ldo;
+    const __half *res; int ldr;
+    int H, W, Cin, CinPad, Cout, act, n_tiles, tiles_per_img, tile_rows;   // tile_rows: LDS rows reserved
+};
+
+template <int BN, int WPX>
+__global__ void __launch_bounds__(256) k_conv3x3_strip(StripArgs a)
+{
+    constexpr int BM = 4 * WPX;
+    constexpr int NW = BN / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int W2 = a.W + 2;
+    const int tile_px = a.tile_rows * W2;
+    __half *actT = (__half *)smem;                               // [tile_rows*(W+2)][LDSROW]
+    __half *wT = actT + (size_t)tile_px * LDSROW;                // [2][BN][LDSROW]
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n_tile = blockIdx.x % a.n_tiles;
+    const int t = blockIdx.x / a.n_tiles;
+    const int b = t / a.tiles_per_img, p0 = (t - b * a.tiles_per_img) * BM;
+    const int HW = a.H * a.W;
+    const int n0 = n_tile * BN;
+    const int oy_first = p0 / a.W;
+    const int p_last = min(p0 + BM, HW) - 1;
+    const int nrows = p_last / a.W - oy_first + 3;               // rows actually needed (<= tile_rows)
+    const int npix = nrows * W2;
+    const int part = tid & 3;
+    const int cpt = a.CinPad >> 5;
+    const size_t wrow = (size_t)9 * a.CinPad;
+
+    constexpr int NAMAX = 12;                                    // uint4 per thread for one chunk of the strip
+    uint4 ra[NAMAX], rw[NW];
+    auto gload_act = [&](int cc) {
+#pragma unroll
+        for (int i = 0; i < NAMAX; ++i) {
+            const int q = (tid >> 2) + 64 * i;
+            ra[i] = make_uint4(0, 0, 0, 0);
+            if (q < npix) {
+                const int r = q / W2, c = q - r * W2;
+                const int iy = oy_first - 1 + r, ix = c - 1;
+                if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W && (cc << 5) + part * 8 < a.Cin)
+                    ra[i] = *reinterpret_cast<const uint4 *>(a.in + ((size_t)(b * a.H + iy) * a.W + ix) * a.ldi + (cc << 5) + part * 8);
+            }
+        }
+    };
+    auto lstore_act = [&]() {
+#pragma unroll
+        for (int i = 0; i < NAMAX; ++i) {
+            const int q = (tid >> 2) + 64 * i;
+            if (q < npix) *reinterpret_cast<uint4 *>(actT + (size_t)q * LDSROW + part * 8) = ra[i];
+        }
+    };
+    auto gload_w = [&](int tap, int cc) {
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int co = n0 + (tid >> 2) + 64 * i;
+            rw[i] = *reinterpret_cast<const uint4 *>(a.w + (size_t)co * wrow + (size_t)tap * a.CinPad + (cc << 5) + part * 8);
+        }
+    };
+    auto lstore_w = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NW; ++i)
+            *reinterpret_cast<uint4 *>(wT + ((size_t)buf * BN + (tid >> 2) + 64 * i) * LDSROW + part * 8) = rw[i];
+    };
+
+    // this lane's B-fragment pixels -> index of the tap-(0,0) source pixel inside the LDS tile
+    int bidx[WPX / 16];
+#pragma unroll
+    for (int j = 0; j < WPX / 16; ++j) {
+        int p = p0 + wv * WPX + 16 * j + (lane & 15);
+        p = min(p, HW - 1);                                      // tail pixels compute a duplicate, never stored
+        const int oy = p / a.W, ox = p - oy * a.W;
+        bidx[j] = ((oy - oy_first) * W2 + ox) * LDSROW + (lane >> 4) * 8;
+    }
+
+    f4 acc[BN / 16][WPX / 16];
+#pragma unroll
+    for (int i = 0; i < BN / 16; ++i)
+#pragma unroll
+        for (int j = 0; j < WPX / 16; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+    gload_act(0);
+    gload_w(0, 0);
+    lstore_act();
+    lstore_w(0);
+    __syncthreads();
+    int s = 0;
+    for (int cc = 0; cc < cpt; ++cc) {
+        const bool more_c = cc + 1 < cpt;
+        if (more_c) gload_act(cc + 1);                           // hidden under the 9 tap steps below
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap, ++s) {
+            const int buf = s & 1;
+            const bool more = more_c || tap < 8;
+            if (more) { if (tap < 8) gload_w(tap + 1, cc); else gload_w(0, cc + 1); }
+            const int dy = tap / 3, dx = tap - dy * 3;
+            const int toff = (dy * W2 + dx) * LDSROW;
+            const __half *wb = wT + ((size_t)buf * BN + (lane & 15)) * LDSROW + (lane >> 4) * 8;
+            h8 bf[WPX / 16];
+#pragma unroll
+            for (int j = 0; j < WPX / 16; ++j) bf[j] = *reinterpret_cast<const h8 *>(actT + bidx[j] + toff);
+#pragma unroll
+            for (int i = 0; i < BN / 16; ++i) {
+                const h8 af = *reinterpret_cast<const h8 *>(wb + i * 16 * LDSROW);
+#pragma unroll
+                for (int j = 0; j < WPX / 16; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[j], acc[i][j], 0, 0, 0);
+            }
+            if (more) lstore_w(buf ^ 1);
+            __syncthreads();
+        }
+        if (more_c) {                                            // every wave is past the last read of the old tile
+            lstore_act();
+            __syncthreads();
+        }
+    }
+
+    constexpr int SROW = BN + 8;
+    __half *stage = (__half *)smem;
+#pragma unroll
+    for (int i = 0; i < BN / 16; ++i) {
+        const int co = 16 * i + (lane >> 4) * 4;
+        const float4 bv = *reinterpret_cast<const float4 *>(a.bias + n0 + co);
+#pragma unroll
+        for (int j = 0; j < WPX / 16; ++j) {
+            float v0 = acc[i][j][0] + bv.x, v1 = acc[i][j][1] + bv.y, v2 = acc[i][j][2] + bv.z, v3 = acc[i][j][3] + bv.w;
+            if (a.act) { v0 = silu_f(v0); v1 = silu_f(v1); v2 = silu_f(v2); v3 = silu_f(v3); }
+            const int px = wv * WPX + 16 * j + (lane & 15);
+            __half2 lo = __floats2half2_rn(v0, v1), hi = __floats2half2_rn(v2, v3);
+            uint2 pk;
+            pk.x = *reinterpret_cast<uint32_t *>(&lo);
+            pk.y = *reinterpret_cast<uint32_t *>(&hi);
+            *reinterpret_cast<uint2 *>(stage + (size_t)px * SROW + co) = pk;
+        }
+    }
+    __syncthreads();
+    constexpr int CPR = BN / 8;
+    const size_t mbase = (size_t)b * HW + p0;
+#pragma unroll 4
+    for (int q = tid; q < BM * CPR; q += 256) {
+        const int row = q / CPR, pc = q - row * CPR;
+        const int co = n0 + pc * 8;
+        if (p0 + row < HW && co < a.Cout) {
+            uint4 v = *reinterpret_cast<const uint4 *>(stage + (size_t)row * SROW + pc * 8);
+            const size_t m = mbase + row;
+            if (a.res) {
+                const uint4 r = *reinterpret_cast<const uint4 *>(a.res + m * a.ldr + co);
+                __half2 *vh = reinterpret_cast<__half2 *>(&v);
+                const __half2 *rh = reinterpret_cast<const __half2 *>(&r);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float2 x = __half22float2(vh[u]), y = __half22float2(rh[u]);
+                    vh[u] = __floats2half2_rn(x.x + y.x, x.y + y.y);
+                }
+            }
+            *reinterpret_cast<uint4 *>(a.out + m * a.ldo + co) = v;
+        }
+    }
+}
+
+template <int BN, int WPX>
+hipError_t launch_strip(StripArgs &a, int batch, hipStream_t s)
+{
+    constexpr int BM = 4 * WPX;
+    a.tile_rows = (BM - 1 + a.W - 1) / a.W + 3;                  // worst case rows a strip can touch, + halo
+    const size_t op = ((size_t)a.tile_rows * (a.W + 2) + 2 * BN) * LDSROW * 2;
+    const size_t st = (size_t)BM * (BN + 8) * 2;
+    const size_t smem = op > st ? op : st;
+    if ((size_t)a.tile_rows * (a.W + 2) > (size_t)12 * 64) return hipErrorInvalidValue;   // NAMAX staging registers
+    static size_t attr = 0;
+    if (smem > attr) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_conv3x3_strip<BN, WPX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        attr = smem;
+    }
+    a.tiles_per_img = rva_ceil_div(a.H * a.W, BM);
+    k_conv3x3_strip<BN, WPX><<<batch * a.tiles_per_img * a.n_tiles, 256, smem, s>>>(a);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Stem: 3x3 stride-2 pad-1 conv on planar [B,3,H,W] fp16 (what K1 writes), Cout <= 64, NHWC out.
 struct StemArgs {
@@ -386,6 +576,20 @@ int rva_conv2d_nhwc_f16(rva_ctx *ctx, const void *in, int ldi, const void *weigh
     // tile choice: weights are padded to a multiple of 64 output channels by the caller (rva_conv_cout_pad)
     const int cpad = rva_ceil_div(Cout, 64) * 64;
     const bool bn128 = cpad % 128 == 0;
+    if (ksize == 3 && stride == 1) {
+        StripArgs sa{};
+        sa.in = a.in; sa.ldi = ldi; sa.w = a.w; sa.bias = bias; sa.out = a.out; sa.ldo = ldo; sa.res = a.res; sa.ldr = ldr;
+        sa.H = H; sa.W = W; sa.Cin = Cin; sa.CinPad = a.CinPad; sa.Cout = Cout; sa.act = act;
+        sa.n_tiles = cpad / (bn128 ? 128 : 64);
+        // 256-pixel strips unless the halo tile would not fit the staging registers / LDS (wide maps)
+        const bool wide = ((255 + W - 1) / W + 3) * (W + 2) > 12 * 64 || (long)batch * rva_ceil_div(H * W, 256) * sa.n_tiles < 512;
+        hipError_t e2;
+        if (bn128) e2 = wide ? launch_strip<128, 32>(sa, batch, s) : launch_strip<128, 64>(sa, batch, s);
+        else e2 = wide ? launch_strip<64, 32>(sa, batch, s) : launch_strip<64, 64>(sa, batch, s);
+        if (e2 == hipSuccess) return RVA_OK;
+        if (e2 != hipErrorInvalidValue) return rva_fail(ctx, RVA_ERR_HIP, "strip conv launch failed: %s", hipGetErrorString(e2));
+        (void)hipGetLastError();   // geometry too wide for the strip kernel: fall through to the gather kernel
+    }
     const int BN = bn128 ? 128 : 64;
     a.n_tiles = cpad / BN;
     // small problems: 128-pixel tiles keep more CUs busy
