@@ -224,89 +224,116 @@ hipError_t launch_conv(const ConvArgs &a, hipStream_t s)
 
 
 // ---------------------------------------------------------------------------------------------------
-// 3x3 stride-1 convolution, halo-strip variant.  A block owns 4*WPX consecutive output pixels (raster
-// order) of ONE image and all BN output channels.  Per 32-channel chunk the input rows the strip
-// touches (+1 halo row above/below, +1 zero column left/right) are staged ONCE in LDS and all nine taps
-// read their B fragments from that tile at a per-tap offset -- 9x fewer L2->LDS bytes than re-gathering
-// per tap, and the next chunk's loads fly under nine MFMA steps.  Weights stream per (chunk, tap) through
-// a double-buffered [BN][32] LDS tile, one step ahead.
-struct StripArgs {
+// Resident-chunk convolution (3x3 stride 1, and 1x1): persistent blocks, one per CU.
+//
+// A work item is (tile, channel chunk).  A tile = 4*WPX consecutive output pixels (raster order; of one
+// image for 3x3, of the flat batch for 1x1) x BN output channels.  For each item ALL operands sit in LDS:
+//   3x3: the input rows the strip touches (+ halo row above/below, + zero column left/right) for CK = 32
+//        channels, and the weights of all nine taps [9][BN][32];
+//   1x1: the tile's pixels for CK = 128 channels and weights [BN][128].
+// The MFMA phase of an item therefore issues no global memory instruction and has no barrier; the NEXT
+// item's operands (next chunk, or the first chunk of the block's next tile) are prefetched into
+// registers at the start of the phase and written to LDS at the item boundary (2 barriers per item).
+// Compared with re-gathering activations per tap this moves 9x fewer bytes from L2 to LDS and hides the
+// load latency behind TAPS * CK/32 MFMA steps instead of one.
+struct ResArgs {
     const __half *in; int ldi;
     const __half *w; const float *bias;
     __half *out; int ldo;
     const __half *res; int ldr;
-    int H, W, Cin, CinPad, Cout, act, n_tiles, tiles_per_img, tile_rows;   // tile_rows: LDS rows reserved
+    int H, W, Cin, CinPad, Cout, act, n_tiles, tiles_per_img, total_tiles, tile_rows, M;
 };
 
-template <int BN, int WPX>
-__global__ void __launch_bounds__(256) k_conv3x3_strip(StripArgs a)
+template <int BN, int WPX, int KS, int CK, int NA>
+__global__ void __launch_bounds__(256, 1) k_conv_res(ResArgs a)
 {
     constexpr int BM = 4 * WPX;
-    constexpr int NW = BN / 64;
+    constexpr int TAPS = KS * KS;
+    constexpr int ROW = CK + 8;               // halfs per LDS row (pad 16 B: conflict-free b128 reads)
+    constexpr int PARTS = CK / 8;             // 16-byte parts per row
+    constexpr int KSTEPS = CK / 32;
+    constexpr int NWT = TAPS * BN * PARTS / 256;   // weight uint4 per thread per item
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int W2 = a.W + 2;
-    const int tile_px = a.tile_rows * W2;
-    __half *actT = (__half *)smem;                               // [tile_rows*(W+2)][LDSROW]
-    __half *wT = actT + (size_t)tile_px * LDSROW;                // [2][BN][LDSROW]
+    const int act_px = KS == 3 ? a.tile_rows * W2 : BM;
+    __half *actT = (__half *)smem;                          // [act_px][ROW]
+    __half *wT = actT + (size_t)act_px * ROW;               // [TAPS][BN][ROW]
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int n_tile = blockIdx.x % a.n_tiles;
-    const int t = blockIdx.x / a.n_tiles;
-    const int b = t / a.tiles_per_img, p0 = (t - b * a.tiles_per_img) * BM;
     const int HW = a.H * a.W;
-    const int n0 = n_tile * BN;
-    const int oy_first = p0 / a.W;
-    const int p_last = min(p0 + BM, HW) - 1;
-    const int nrows = p_last / a.W - oy_first + 3;               // rows actually needed (<= tile_rows)
-    const int npix = nrows * W2;
-    const int part = tid & 3;
-    const int cpt = a.CinPad >> 5;
-    const size_t wrow = (size_t)9 * a.CinPad;
+    const int cpt = a.CinPad / CK;
+    const size_t wrow = (size_t)TAPS * a.CinPad;
 
-    constexpr int NAMAX = 12;                                    // uint4 per thread for one chunk of the strip
-    uint4 ra[NAMAX], rw[NW];
-    auto gload_act = [&](int cc) {
+    struct Tile { int n0, b, p0, oy_first, npix; };
+    auto decode = [&](int t) {
+        Tile T;
+        T.n0 = (t % a.n_tiles) * BN;
+        const int m = t / a.n_tiles;
+        if (KS == 3) {
+            T.b = m / a.tiles_per_img;
+            T.p0 = (m - T.b * a.tiles_per_img) * BM;
+            T.oy_first = T.p0 / a.W;
+            const int p_last = min(T.p0 + BM, HW) - 1;
+            T.npix = (p_last / a.W - T.oy_first + 3) * W2;
+        } else {
+            T.b = 0; T.p0 = m * BM; T.oy_first = 0; T.npix = min(BM, a.M - T.p0);
+        }
+        return T;
+    };
+
+    uint4 ra[NA], rw[NWT];
+    auto prefetch_act = [&](const Tile &T, int cc) {
 #pragma unroll
-        for (int i = 0; i < NAMAX; ++i) {
-            const int q = (tid >> 2) + 64 * i;
+        for (int i = 0; i < NA; ++i) {
+            const int q = tid + 256 * i;
+            const int px = q / PARTS, part = q - px * PARTS;
             ra[i] = make_uint4(0, 0, 0, 0);
-            if (q < npix) {
-                const int r = q / W2, c = q - r * W2;
-                const int iy = oy_first - 1 + r, ix = c - 1;
-                if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W && (cc << 5) + part * 8 < a.Cin)
-                    ra[i] = *reinterpret_cast<const uint4 *>(a.in + ((size_t)(b * a.H + iy) * a.W + ix) * a.ldi + (cc << 5) + part * 8);
+            if (px < T.npix && cc * CK + part * 8 < a.Cin) {
+                if (KS == 3) {
+                    const int r = px / W2, c = px - r * W2;
+                    const int iy = T.oy_first - 1 + r, ix = c - 1;
+                    if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+                        ra[i] = *reinterpret_cast<const uint4 *>(a.in + ((size_t)(T.b * a.H + iy) * a.W + ix) * a.ldi + cc * CK + part * 8);
+                } else {
+                    ra[i] = *reinterpret_cast<const uint4 *>(a.in + (size_t)(T.p0 + px) * a.ldi + cc * CK + part * 8);
+                }
             }
         }
     };
-    auto lstore_act = [&]() {
+    auto store_act = [&](const Tile &T) {
 #pragma unroll
-        for (int i = 0; i < NAMAX; ++i) {
-            const int q = (tid >> 2) + 64 * i;
-            if (q < npix) *reinterpret_cast<uint4 *>(actT + (size_t)q * LDSROW + part * 8) = ra[i];
+        for (int i = 0; i < NA; ++i) {
+            const int q = tid + 256 * i;
+            const int px = q / PARTS, part = q - px * PARTS;
+            if (px < (KS == 3 ? T.npix : BM)) *reinterpret_cast<uint4 *>(actT + (size_t)px * ROW + part * 8) = ra[i];
         }
     };
-    auto gload_w = [&](int tap, int cc) {
+    auto prefetch_w = [&](int n0, int cc) {
 #pragma unroll
-        for (int i = 0; i < NW; ++i) {
-            const int co = n0 + (tid >> 2) + 64 * i;
-            rw[i] = *reinterpret_cast<const uint4 *>(a.w + (size_t)co * wrow + (size_t)tap * a.CinPad + (cc << 5) + part * 8);
+        for (int i = 0; i < NWT; ++i) {
+            const int q = tid + 256 * i;                   // (tap, co, part)
+            const int part = q % PARTS, rowi = q / PARTS, co = rowi % BN, tap = rowi / BN;
+            rw[i] = *reinterpret_cast<const uint4 *>(a.w + (size_t)(n0 + co) * wrow + (size_t)tap * a.CinPad + cc * CK + part * 8);
         }
     };
-    auto lstore_w = [&](int buf) {
+    auto store_w = [&]() {
 #pragma unroll
-        for (int i = 0; i < NW; ++i)
-            *reinterpret_cast<uint4 *>(wT + ((size_t)buf * BN + (tid >> 2) + 64 * i) * LDSROW + part * 8) = rw[i];
+        for (int i = 0; i < NWT; ++i) {
+            const int q = tid + 256 * i;
+            const int part = q % PARTS, rowi = q / PARTS;
+            *reinterpret_cast<uint4 *>(wT + (size_t)rowi * ROW + part * 8) = rw[i];
+        }
     };
 
-    // this lane's B-fragment pixels -> index of the tap-(0,0) source pixel inside the LDS tile
-    int bidx[WPX / 16];
-#pragma unroll
-    for (int j = 0; j < WPX / 16; ++j) {
-        int p = p0 + wv * WPX + 16 * j + (lane & 15);
-        p = min(p, HW - 1);                                      // tail pixels compute a duplicate, never stored
-        const int oy = p / a.W, ox = p - oy * a.W;
-        bidx[j] = ((oy - oy_first) * W2 + ox) * LDSROW + (lane >> 4) * 8;
-    }
+    int t = blockIdx.x;
+    if (t >= a.total_tiles) return;
+    Tile T = decode(t);
+    int cc = 0;
+    prefetch_act(T, 0);
+    prefetch_w(T.n0, 0);
+    store_act(T);
+    store_w();
+    __syncthreads();
 
     f4 acc[BN / 16][WPX / 16];
 #pragma unroll
@@ -314,101 +341,137 @@ __global__ void __launch_bounds__(256) k_conv3x3_strip(StripArgs a)
 #pragma unroll
         for (int j = 0; j < WPX / 16; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
 
-    gload_act(0);
-    gload_w(0, 0);
-    lstore_act();
-    lstore_w(0);
-    __syncthreads();
-    int s = 0;
-    for (int cc = 0; cc < cpt; ++cc) {
-        const bool more_c = cc + 1 < cpt;
-        if (more_c) gload_act(cc + 1);                           // hidden under the 9 tap steps below
-#pragma unroll 1
-        for (int tap = 0; tap < 9; ++tap, ++s) {
-            const int buf = s & 1;
-            const bool more = more_c || tap < 8;
-            if (more) { if (tap < 8) gload_w(tap + 1, cc); else gload_w(0, cc + 1); }
-            const int dy = tap / 3, dx = tap - dy * 3;
-            const int toff = (dy * W2 + dx) * LDSROW;
-            const __half *wb = wT + ((size_t)buf * BN + (lane & 15)) * LDSROW + (lane >> 4) * 8;
-            h8 bf[WPX / 16];
-#pragma unroll
-            for (int j = 0; j < WPX / 16; ++j) bf[j] = *reinterpret_cast<const h8 *>(actT + bidx[j] + toff);
-#pragma unroll
-            for (int i = 0; i < BN / 16; ++i) {
-                const h8 af = *reinterpret_cast<const h8 *>(wb + i * 16 * LDSROW);
-#pragma unroll
-                for (int j = 0; j < WPX / 16; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[j], acc[i][j], 0, 0, 0);
-            }
-            if (more) lstore_w(buf ^ 1);
-            __syncthreads();
+    while (true) {
+        // ---- next work item: prefetch under this item's MFMA phase
+        int nt = t, ncc = cc + 1;
+        if (ncc == cpt) { ncc = 0; nt = t + gridDim.x; }
+        const bool has_next = nt < a.total_tiles;
+        Tile TN = T;
+        if (has_next) {
+            if (nt != t) TN = decode(nt);
+            prefetch_act(TN, ncc);
+            if (cpt > 1 || TN.n0 != T.n0) prefetch_w(TN.n0, ncc);
         }
-        if (more_c) {                                            // every wave is past the last read of the old tile
-            lstore_act();
-            __syncthreads();
-        }
-    }
-
-    constexpr int SROW = BN + 8;
-    __half *stage = (__half *)smem;
-#pragma unroll
-    for (int i = 0; i < BN / 16; ++i) {
-        const int co = 16 * i + (lane >> 4) * 4;
-        const float4 bv = *reinterpret_cast<const float4 *>(a.bias + n0 + co);
+        // ---- MFMA phase: everything from LDS
+        int bidx[WPX / 16];
 #pragma unroll
         for (int j = 0; j < WPX / 16; ++j) {
-            float v0 = acc[i][j][0] + bv.x, v1 = acc[i][j][1] + bv.y, v2 = acc[i][j][2] + bv.z, v3 = acc[i][j][3] + bv.w;
-            if (a.act) { v0 = silu_f(v0); v1 = silu_f(v1); v2 = silu_f(v2); v3 = silu_f(v3); }
-            const int px = wv * WPX + 16 * j + (lane & 15);
-            __half2 lo = __floats2half2_rn(v0, v1), hi = __floats2half2_rn(v2, v3);
-            uint2 pk;
-            pk.x = *reinterpret_cast<uint32_t *>(&lo);
-            pk.y = *reinterpret_cast<uint32_t *>(&hi);
-            *reinterpret_cast<uint2 *>(stage + (size_t)px * SROW + co) = pk;
+            const int lp = wv * WPX + 16 * j + (lane & 15);
+            if (KS == 3) {
+                const int p = min(T.p0 + lp, HW - 1);      // tail pixels recompute the last pixel, never stored
+                const int oy = p / a.W, ox = p - oy * a.W;
+                bidx[j] = ((oy - T.oy_first) * W2 + ox) * ROW + (lane >> 4) * 8;
+            } else {
+                bidx[j] = lp * ROW + (lane >> 4) * 8;
+            }
         }
-    }
-    __syncthreads();
-    constexpr int CPR = BN / 8;
-    const size_t mbase = (size_t)b * HW + p0;
-#pragma unroll 4
-    for (int q = tid; q < BM * CPR; q += 256) {
-        const int row = q / CPR, pc = q - row * CPR;
-        const int co = n0 + pc * 8;
-        if (p0 + row < HW && co < a.Cout) {
-            uint4 v = *reinterpret_cast<const uint4 *>(stage + (size_t)row * SROW + pc * 8);
-            const size_t m = mbase + row;
-            if (a.res) {
-                const uint4 r = *reinterpret_cast<const uint4 *>(a.res + m * a.ldr + co);
-                __half2 *vh = reinterpret_cast<__half2 *>(&v);
-                const __half2 *rh = reinterpret_cast<const __half2 *>(&r);
+        const __half *wb = wT + (size_t)(lane & 15) * ROW + (lane >> 4) * 8;
+#pragma unroll 1
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int toff = KS == 3 ? ((tap / 3) * W2 + (tap % 3)) * ROW : 0;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float2 x = __half22float2(vh[u]), y = __half22float2(rh[u]);
-                    vh[u] = __floats2half2_rn(x.x + y.x, x.y + y.y);
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+                h8 bf[WPX / 16];
+#pragma unroll
+                for (int j = 0; j < WPX / 16; ++j) bf[j] = *reinterpret_cast<const h8 *>(actT + bidx[j] + toff + ks * 32);
+#pragma unroll
+                for (int i = 0; i < BN / 16; ++i) {
+                    const h8 af = *reinterpret_cast<const h8 *>(wb + (size_t)(tap * BN + i * 16) * ROW + ks * 32);
+#pragma unroll
+                    for (int j = 0; j < WPX / 16; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[j], acc[i][j], 0, 0, 0);
                 }
             }
-            *reinterpret_cast<uint4 *>(a.out + m * a.ldo + co) = v;
         }
+        __syncthreads();                                   // every wave is done reading this item's operands
+        if (cc == cpt - 1) {
+            // ---- epilogue of the tile: bias + SiLU, transpose through LDS, vector stores (+ residual)
+            constexpr int SROW = BN + 8;
+            __half *stage = (__half *)smem;
+#pragma unroll
+            for (int i = 0; i < BN / 16; ++i) {
+                const int co = 16 * i + (lane >> 4) * 4;
+                const float4 bv = *reinterpret_cast<const float4 *>(a.bias + T.n0 + co);
+#pragma unroll
+                for (int j = 0; j < WPX / 16; ++j) {
+                    float v0 = acc[i][j][0] + bv.x, v1 = acc[i][j][1] + bv.y, v2 = acc[i][j][2] + bv.z, v3 = acc[i][j][3] + bv.w;
+                    if (a.act) { v0 = silu_f(v0); v1 = silu_f(v1); v2 = silu_f(v2); v3 = silu_f(v3); }
+                    acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+                    const int px = wv * WPX + 16 * j + (lane & 15);
+                    __half2 lo = __floats2half2_rn(v0, v1), hi = __floats2half2_rn(v2, v3);
+                    uint2 pk;
+                    pk.x = *reinterpret_cast<uint32_t *>(&lo);
+                    pk.y = *reinterpret_cast<uint32_t *>(&hi);
+                    *reinterpret_cast<uint2 *>(stage + (size_t)px * SROW + co) = pk;
+                }
+            }
+            __syncthreads();
+            constexpr int CPR = BN / 8;
+            const size_t mbase = KS == 3 ? (size_t)T.b * HW + T.p0 : (size_t)T.p0;
+            const int valid = KS == 3 ? min(BM, HW - T.p0) : min(BM, a.M - T.p0);
+#pragma unroll 4
+            for (int q = tid; q < BM * CPR; q += 256) {
+                const int row = q / CPR, pc = q - row * CPR;
+                const int co = T.n0 + pc * 8;
+                if (row < valid && co < a.Cout) {
+                    uint4 v = *reinterpret_cast<const uint4 *>(stage + (size_t)row * SROW + pc * 8);
+                    const size_t m = mbase + row;
+                    if (a.res) {
+                        const uint4 r = *reinterpret_cast<const uint4 *>(a.res + m * a.ldr + co);
+                        __half2 *vh = reinterpret_cast<__half2 *>(&v);
+                        const __half2 *rh = reinterpret_cast<const __half2 *>(&r);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const float2 x = __half22float2(vh[u]), y = __half22float2(rh[u]);
+                            vh[u] = __floats2half2_rn(x.x + y.x, x.y + y.y);
+                        }
+                    }
+                    *reinterpret_cast<uint4 *>(a.out + m * a.ldo + co) = v;
+                }
+            }
+            __syncthreads();                               // staging area free again
+        }
+        if (!has_next) break;
+        store_act(TN);
+        if (cpt > 1 || TN.n0 != T.n0) store_w();
+        __syncthreads();
+        T = TN; t = nt; cc = ncc;
     }
 }
 
-template <int BN, int WPX>
-hipError_t launch_strip(StripArgs &a, int batch, hipStream_t s)
+template <int BN, int WPX, int KS, int CK, int NA>
+hipError_t launch_res(ResArgs &a, int batch, int num_cus, hipStream_t s)
 {
     constexpr int BM = 4 * WPX;
-    a.tile_rows = (BM - 1 + a.W - 1) / a.W + 3;                  // worst case rows a strip can touch, + halo
-    const size_t op = ((size_t)a.tile_rows * (a.W + 2) + 2 * BN) * LDSROW * 2;
+    constexpr int ROW = CK + 8;
+    size_t act_px;
+    if (KS == 3) {
+        a.tile_rows = (BM - 1 + a.W - 1) / a.W + 3;         // worst-case rows a strip touches, + halo
+        act_px = (size_t)a.tile_rows * (a.W + 2);
+        a.tiles_per_img = rva_ceil_div(a.H * a.W, BM);
+        a.total_tiles = batch * a.tiles_per_img * a.n_tiles;
+    } else {
+        a.tile_rows = 0;
+        act_px = BM;
+        a.tiles_per_img = 0;
+        a.total_tiles = rva_ceil_div(a.M, BM) * a.n_tiles;
+    }
+    if (act_px * (CK / 8) > (size_t)NA * 256) return hipErrorInvalidValue;        // staging registers
+    const size_t op = (act_px + (size_t)KS * KS * BN) * ROW * 2;
     const size_t st = (size_t)BM * (BN + 8) * 2;
     const size_t smem = op > st ? op : st;
-    if ((size_t)a.tile_rows * (a.W + 2) > (size_t)12 * 64) return hipErrorInvalidValue;   // NAMAX staging registers
+    if (smem > 160 * 1024) return hipErrorInvalidValue;
     static size_t attr = 0;
     if (smem > attr) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_conv3x3_strip<BN, WPX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipError_t e = hipFuncSetAttribute((const void *)k_conv_res<BN, WPX, KS, CK, NA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
         attr = smem;
     }
-    a.tiles_per_img = rva_ceil_div(a.H * a.W, BM);
-    k_conv3x3_strip<BN, WPX><<<batch * a.tiles_per_img * a.n_tiles, 256, smem, s>>>(a);
+    // persistent grid: one block per CU, a multiple of n_tiles so a block keeps its weight columns
+    int grid = num_cus - num_cus % a.n_tiles;
+    if (grid <= 0) grid = a.n_tiles;
+    if (grid > a.total_tiles) grid = a.total_tiles;
+    k_conv_res<BN, WPX, KS, CK, NA><<<grid, 256, smem, s>>>(a);
     return hipGetLastError();
 }
 
@@ -576,22 +639,39 @@ int rva_conv2d_nhwc_f16(rva_ctx *ctx, const void *in, int ldi, const void *weigh
     // tile choice: weights are padded to a multiple of 64 output channels by the caller (rva_conv_cout_pad)
     const int cpad = rva_ceil_div(Cout, 64) * 64;
     const bool bn128 = cpad % 128 == 0;
-    if (ksize == 3 && stride == 1) {
-        StripArgs sa{};
-        sa.in = a.in; sa.ldi = ldi; sa.w = a.w; sa.bias = bias; sa.out = a.out; sa.ldo = ldo; sa.res = a.res; sa.ldr = ldr;
-        sa.H = H; sa.W = W; sa.Cin = Cin; sa.CinPad = a.CinPad; sa.Cout = Cout; sa.act = act;
-        sa.n_tiles = cpad / (bn128 ? 128 : 64);
-        // 256-pixel strips unless the halo tile would not fit the staging registers / LDS (wide maps)
-        const bool wide = ((255 + W - 1) / W + 3) * (W + 2) > 12 * 64 || (long)batch * rva_ceil_div(H * W, 256) * sa.n_tiles < 512;
-        hipError_t e2;
-        if (bn128) e2 = wide ? launch_strip<128, 32>(sa, batch, s) : launch_strip<128, 64>(sa, batch, s);
-        else e2 = wide ? launch_strip<64, 32>(sa, batch, s) : launch_strip<64, 64>(sa, batch, s);
+    if (stride == 1) {
+        ResArgs ra{};
+        ra.in = a.in; ra.ldi = ldi; ra.w = a.w; ra.bias = bias; ra.out = a.out; ra.ldo = ldo; ra.res = a.res; ra.ldr = ldr;
+        ra.H = H; ra.W = W; ra.Cin = Cin; ra.CinPad = a.CinPad; ra.Cout = Cout; ra.act = act; ra.M = a.M;
+        static int num_cus = 0;
+        if (!num_cus) {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess) num_cus = prop.multiProcessorCount;
+            if (num_cus <= 0) num_cus = 256;
+        }
+        hipError_t e2 = hipErrorInvalidValue;
+        if (ksize == 3) {
+            // tile = 256 px x 128 ch when that yields enough tiles for every CU, else smaller tiles
+            const long t256 = (long)batch * rva_ceil_div(H * W, 256), t128 = (long)batch * rva_ceil_div(H * W, 128);
+            if (bn128 && t256 * (cpad / 128) >= 2 * num_cus) { ra.n_tiles = cpad / 128; e2 = launch_res<128, 64, 3, 32, 9>(ra, batch, num_cus, s); }
+            if (e2 == hipErrorInvalidValue && t256 * (cpad / 64) >= 2 * num_cus) { ra.n_tiles = cpad / 64; e2 = launch_res<64, 64, 3, 32, 9>(ra, batch, num_cus, s); }
+            if (e2 == hipErrorInvalidValue && bn128 && t128 * (cpad / 128) >= 2 * num_cus) { ra.n_tiles = cpad / 128; e2 = launch_res<128, 32, 3, 32, 11>(ra, batch, num_cus, s); }
+            if (e2 == hipErrorInvalidValue) { ra.n_tiles = cpad / 64; e2 = launch_res<64, 32, 3, 32, 11>(ra, batch, num_cus, s); }
+        } else if (a.CinPad % 128 == 0) {
+            const long t256 = rva_ceil_div(a.M, 256);
+            if (bn128 && t256 * (cpad / 128) >= 2 * num_cus) { ra.n_tiles = cpad / 128; e2 = launch_res<128, 64, 1, 128, 16>(ra, batch, num_cus, s); }
+            if (e2 == hipErrorInvalidValue && t256 * (cpad / 64) >= 2 * num_cus) { ra.n_tiles = cpad / 64; e2 = launch_res<64, 64, 1, 128, 16>(ra, batch, num_cus, s); }
+            if (e2 == hipErrorInvalidValue) { ra.n_tiles = cpad / 64; e2 = launch_res<64, 32, 1, 128, 8>(ra, batch, num_cus, s); }
+        } else {
+            const long t256 = rva_ceil_div(a.M, 256);
+            if (t256 * (cpad / 64) >= 2 * num_cus) { ra.n_tiles = cpad / 64; e2 = launch_res<64, 64, 1, 32, 4>(ra, batch, num_cus, s); }
+            else { ra.n_tiles = cpad / 64; e2 = launch_res<64, 32, 1, 32, 2>(ra, batch, num_cus, s); }
+        }
         if (e2 == hipSuccess) return RVA_OK;
-        if (e2 != hipErrorInvalidValue) return rva_fail(ctx, RVA_ERR_HIP, "strip conv launch failed: %s", hipGetErrorString(e2));
-        (void)hipGetLastError();   // geometry too wide for the strip kernel: fall through to the gather kernel
+        if (e2 != hipErrorInvalidValue) return rva_fail(ctx, RVA_ERR_HIP, "resident conv launch failed: %s", hipGetErrorString(e2));
+        (void)hipGetLastError();   // geometry does not fit the resident kernel: fall through to the gather kernel
     }
-    const int BN = bn128 ? 128 : 64;
-    a.n_tiles = cpad / BN;
+    a.n_tiles = cpad / (bn128 ? 128 : 64);
     // small problems: 128-pixel tiles keep more CUs busy
     const bool small = (long)rva_ceil_div(a.M, 256) * a.n_tiles < 512;
     const int BM = small ? 128 : 256;
@@ -602,7 +682,6 @@ int rva_conv2d_nhwc_f16(rva_ctx *ctx, const void *in, int ldi, const void *weigh
     if (bn128) e = small ? RVA_CONV(128, 32) : RVA_CONV(128, 64);
     else e = small ? RVA_CONV(64, 32) : RVA_CONV(64, 64);
 #undef RVA_CONV
-    (void)BN;
     if (e != hipSuccess) return rva_fail(ctx, RVA_ERR_HIP, "conv launch failed: %s", hipGetErrorString(e));
     return RVA_OK;
 }
