@@ -211,6 +211,11 @@ int rva_conv_cout_pad(int Cout);
 int rva_conv2d_nhwc_f16(rva_ctx *ctx, const void *in, int ldi, const void *weights, const float *bias,
                         void *out, int ldo, const void *residual, int ldr, int batch, int H, int W, int Cin,
                         int Cout, int ksize, int stride, int act, rva_stream_t stream);
+/* Same with an explicit kernel variant (0 = heuristic; 1-4 gather tiles, 5-8 resident-chunk tiles): lets
+ * a plan time the applicable variants per layer once and keep the fastest.  RVA_ERR_ARG if not applicable. */
+int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *weights, const float *bias,
+                          void *out, int ldo, const void *residual, int ldr, int batch, int H, int W, int Cin,
+                          int Cout, int ksize, int stride, int act, int variant, rva_stream_t stream);
 int rva_stem_conv_f16(rva_ctx *ctx, const void *in_planar, const float *weights, const float *bias,
                       void *out, int ldo, int batch, int H, int W, int Cout, rva_stream_t stream);
 int rva_maxpool5_nhwc_f16(rva_ctx *ctx, const void *in, int ldi, void *out, int ldo, int batch, int H,

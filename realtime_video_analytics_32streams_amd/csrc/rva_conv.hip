@@ -27,12 +27,18 @@
 // torch module within an fp16 tolerance, never bit-for-bit.
 #include <hip/hip_fp16.h>
 
+#include <cstdlib>
+
 #include "rva_internal.h"
 
 namespace {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f4 __attribute__((ext_vector_type(4)));
+// NOTE: staging registers use this native vector, not HIP's uint4 struct: assigning a dereferenced
+// `const uint4*` into an array element lowers to a memcpy that SROA does not split, the array then lives in
+// scratch and every prefetch load is followed by vmcnt(0) + scratch_store (serialised loads).
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 
 struct ConvArgs {
     const __half *in; int ldi;
@@ -97,33 +103,33 @@ __global__ void __launch_bounds__(256) k_conv_mfma(ConvArgs a)
     const int nsteps = TAPS * cpt;
     const size_t wrow = (size_t)TAPS * a.CinPad;
 
-    uint4 ra[NA], rw[NW];
+    u4 ra[NA], rw[NW];
     auto gload = [&](int tap, int cc) {
         const int dy = KS == 1 ? 0 : tap / KS, dx = KS == 1 ? 0 : tap - dy * KS;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int iy = iy0[i] + dy, ix = ix0[i] + dx;
             const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W && (cc << 5) + part * 8 < a.Cin;
-            ra[i] = make_uint4(0, 0, 0, 0);
+            ra[i] = u4{0u, 0u, 0u, 0u};
             if (ok) {
                 const __half *p = a.in + (size_t)(pix0[i] + dy * a.W + dx) * a.ldi + (cc << 5) + part * 8;
-                ra[i] = *reinterpret_cast<const uint4 *>(p);
+                ra[i] = *reinterpret_cast<const u4 *>(p);
             }
         }
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
             const int co = n0 + (tid >> 2) + 64 * i;
             const __half *p = a.w + (size_t)co * wrow + (size_t)tap * a.CinPad + (cc << 5) + part * 8;
-            rw[i] = *reinterpret_cast<const uint4 *>(p);
+            rw[i] = *reinterpret_cast<const u4 *>(p);
         }
     };
     auto lstore = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < NA; ++i)
-            *reinterpret_cast<uint4 *>(actT + ((size_t)buf * BM + (tid >> 2) + 64 * i) * LDSROW + part * 8) = ra[i];
+            *reinterpret_cast<u4 *>(actT + ((size_t)buf * BM + (tid >> 2) + 64 * i) * LDSROW + part * 8) = ra[i];
 #pragma unroll
         for (int i = 0; i < NW; ++i)
-            *reinterpret_cast<uint4 *>(wT + ((size_t)buf * BN + (tid >> 2) + 64 * i) * LDSROW + part * 8) = rw[i];
+            *reinterpret_cast<u4 *>(wT + ((size_t)buf * BN + (tid >> 2) + 64 * i) * LDSROW + part * 8) = rw[i];
     };
 
     f4 acc[BN / 16][WPX / 16];
@@ -242,6 +248,7 @@ struct ResArgs {
     __half *out; int ldo;
     const __half *res; int ldr;
     int H, W, Cin, CinPad, Cout, act, n_tiles, tiles_per_img, total_tiles, tile_rows, M;
+    int dbg;   // timing-only ablation switches (RVA_CONV_DBG): 1 = skip MFMA phase, 2 = skip prefetch loads, 4 = skip epilogue
 };
 
 template <int BN, int WPX, int KS, int CK, int NA>
@@ -281,21 +288,21 @@ __global__ void __launch_bounds__(256, 1) k_conv_res(ResArgs a)
         return T;
     };
 
-    uint4 ra[NA], rw[NWT];
+    u4 ra[NA], rw[NWT];
     auto prefetch_act = [&](const Tile &T, int cc) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int q = tid + 256 * i;
             const int px = q / PARTS, part = q - px * PARTS;
-            ra[i] = make_uint4(0, 0, 0, 0);
+            ra[i] = u4{0u, 0u, 0u, 0u};
             if (px < T.npix && cc * CK + part * 8 < a.Cin) {
                 if (KS == 3) {
                     const int r = px / W2, c = px - r * W2;
                     const int iy = T.oy_first - 1 + r, ix = c - 1;
                     if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
-                        ra[i] = *reinterpret_cast<const uint4 *>(a.in + ((size_t)(T.b * a.H + iy) * a.W + ix) * a.ldi + cc * CK + part * 8);
+                        ra[i] = *reinterpret_cast<const u4 *>(a.in + ((size_t)(T.b * a.H + iy) * a.W + ix) * a.ldi + cc * CK + part * 8);
                 } else {
-                    ra[i] = *reinterpret_cast<const uint4 *>(a.in + (size_t)(T.p0 + px) * a.ldi + cc * CK + part * 8);
+                    ra[i] = *reinterpret_cast<const u4 *>(a.in + (size_t)(T.p0 + px) * a.ldi + cc * CK + part * 8);
                 }
             }
         }
@@ -305,7 +312,7 @@ __global__ void __launch_bounds__(256, 1) k_conv_res(ResArgs a)
         for (int i = 0; i < NA; ++i) {
             const int q = tid + 256 * i;
             const int px = q / PARTS, part = q - px * PARTS;
-            if (px < (KS == 3 ? T.npix : BM)) *reinterpret_cast<uint4 *>(actT + (size_t)px * ROW + part * 8) = ra[i];
+            if (px < (KS == 3 ? T.npix : BM)) *reinterpret_cast<u4 *>(actT + (size_t)px * ROW + part * 8) = ra[i];
         }
     };
     auto prefetch_w = [&](int n0, int cc) {
@@ -313,7 +320,7 @@ __global__ void __launch_bounds__(256, 1) k_conv_res(ResArgs a)
         for (int i = 0; i < NWT; ++i) {
             const int q = tid + 256 * i;                   // (tap, co, part)
             const int part = q % PARTS, rowi = q / PARTS, co = rowi % BN, tap = rowi / BN;
-            rw[i] = *reinterpret_cast<const uint4 *>(a.w + (size_t)(n0 + co) * wrow + (size_t)tap * a.CinPad + cc * CK + part * 8);
+            rw[i] = *reinterpret_cast<const u4 *>(a.w + (size_t)(n0 + co) * wrow + (size_t)tap * a.CinPad + cc * CK + part * 8);
         }
     };
     auto store_w = [&]() {
@@ -321,7 +328,7 @@ __global__ void __launch_bounds__(256, 1) k_conv_res(ResArgs a)
         for (int i = 0; i < NWT; ++i) {
             const int q = tid + 256 * i;
             const int part = q % PARTS, rowi = q / PARTS;
-            *reinterpret_cast<uint4 *>(wT + (size_t)rowi * ROW + part * 8) = rw[i];
+            *reinterpret_cast<u4 *>(wT + (size_t)rowi * ROW + part * 8) = rw[i];
         }
     };
 
@@ -347,10 +354,10 @@ __global__ void __launch_bounds__(256, 1) k_conv_res(ResArgs a)
         if (ncc == cpt) { ncc = 0; nt = t + gridDim.x; }
         const bool has_next = nt < a.total_tiles;
         Tile TN = T;
-        if (has_next) {
+        if (has_next && !(a.dbg & 2)) {
             if (nt != t) TN = decode(nt);
             prefetch_act(TN, ncc);
-            if (cpt > 1 || TN.n0 != T.n0) prefetch_w(TN.n0, ncc);
+            prefetch_w(TN.n0, ncc);   // unconditional: a conditional definition keeps the staging array in scratch
         }
         // ---- MFMA phase: everything from LDS
         int bidx[WPX / 16];
@@ -366,10 +373,11 @@ __global__ void __launch_bounds__(256, 1) k_conv_res(ResArgs a)
             }
         }
         const __half *wb = wT + (size_t)(lane & 15) * ROW + (lane >> 4) * 8;
-#pragma unroll 1
-        for (int tap = 0; tap < TAPS; ++tap) {
-            const int toff = KS == 3 ? ((tap / 3) * W2 + (tap % 3)) * ROW : 0;
 #pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            if (a.dbg & 1) break;
+            const int toff = KS == 3 ? ((tap / 3) * W2 + (tap % 3)) * ROW : 0;
+#pragma unroll 1
             for (int ks = 0; ks < KSTEPS; ++ks) {
                 h8 bf[WPX / 16];
 #pragma unroll
@@ -384,7 +392,7 @@ __global__ void __launch_bounds__(256, 1) k_conv_res(ResArgs a)
             }
         }
         __syncthreads();                                   // every wave is done reading this item's operands
-        if (cc == cpt - 1) {
+        if (cc == cpt - 1 && !(a.dbg & 4)) {
             // ---- epilogue of the tile: bias + SiLU, transpose through LDS, vector stores (+ residual)
             constexpr int SROW = BN + 8;
             __half *stage = (__half *)smem;
@@ -429,11 +437,12 @@ __global__ void __launch_bounds__(256, 1) k_conv_res(ResArgs a)
                     *reinterpret_cast<uint4 *>(a.out + m * a.ldo + co) = v;
                 }
             }
-            __syncthreads();                               // staging area free again
+            // staging area free again once every wave's LDS reads are done; the global stores stay in flight
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
         if (!has_next) break;
         store_act(TN);
-        if (cpt > 1 || TN.n0 != T.n0) store_w();
+        store_w();
         __syncthreads();
         T = TN; t = nt; cc = ncc;
     }
@@ -484,38 +493,46 @@ struct StemArgs {
 
 __global__ void __launch_bounds__(256) k_stem(StemArgs a)
 {
+    // block = 8 x 32 output pixels of one image; the 17 x 65 x 3 input patch is staged in LDS with
+    // coalesced row loads, weights/bias sit in LDS too (broadcast reads)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float *sw = (float *)smem;                      // [Cout][28]
-    for (int i = threadIdx.x; i < a.Cout * 27; i += 256) sw[(i / 27) * 28 + i % 27] = a.w[i];
-    for (int i = threadIdx.x; i < a.Cout; i += 256) sw[i * 28 + 27] = a.bias[i];
+    float *sw = (float *)smem;                               // [Cout][28]
+    __half *tile = (__half *)(sw + a.Cout * 28);             // [3][17][66]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < a.Cout * 27; i += 256) sw[(i / 27) * 28 + i % 27] = a.w[i];
+    for (int i = tid; i < a.Cout; i += 256) sw[i * 28 + 27] = a.bias[i];
+    const int tiles_x = (a.Wo + 31) >> 5;
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, b = blockIdx.y;
+    const int ox0 = tx * 32, oy0 = ty * 8;
+    const int ix0 = ox0 * 2 - 1, iy0 = oy0 * 2 - 1;
+    for (int i = tid; i < 3 * 17 * 65; i += 256) {
+        const int c = i / (17 * 65), r = (i / 65) % 17, x = i % 65;
+        const int iy = iy0 + r, ix = ix0 + x;
+        __half v = __float2half(0.f);
+        if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) v = a.in[((size_t)(b * 3 + c) * a.H + iy) * a.W + ix];
+        tile[(c * 17 + r) * 66 + x] = v;
+    }
     __syncthreads();
-    const int m = blockIdx.x * 256 + threadIdx.x;
-    const int M = a.B * a.Ho * a.Wo;
-    if (m >= M) return;
-    const int b = m / (a.Ho * a.Wo), rem = m - b * a.Ho * a.Wo, oy = rem / a.Wo, ox = rem - oy * a.Wo;
+    const int lx = tid & 31, ly = tid >> 5;
+    const int ox = ox0 + lx, oy = oy0 + ly;
+    if (ox >= a.Wo || oy >= a.Ho) return;
     float x[27];
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int iy = oy * 2 - 1 + ky, ix = ox * 2 - 1 + kx;
-                float v = 0.f;
-                if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
-                    v = __half2float(a.in[((size_t)(b * 3 + c) * a.H + iy) * a.W + ix]);
-                x[c * 9 + ky * 3 + kx] = v;
-            }
-    __half *o = a.out + (size_t)m * a.ldo;
+            for (int kx = 0; kx < 3; ++kx) x[c * 9 + ky * 3 + kx] = __half2float(tile[(c * 17 + ly * 2 + ky) * 66 + lx * 2 + kx]);
+    __half *o = a.out + ((size_t)(b * a.Ho + oy) * a.Wo + ox) * a.ldo;
     for (int co = 0; co < a.Cout; co += 8) {
         alignas(16) __half r[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const float *wr = sw + (co + u) * 28;
-            float s = wr[27];
+            float sacc = wr[27];
 #pragma unroll
-            for (int k = 0; k < 27; ++k) s = fmaf(wr[k], x[k], s);
-            r[u] = __float2half_rn(silu_f(s));
+            for (int k = 0; k < 27; ++k) sacc = fmaf(wr[k], x[k], sacc);
+            r[u] = __float2half_rn(silu_f(sacc));
         }
         *reinterpret_cast<uint4 *>(o + co) = *reinterpret_cast<const uint4 *>(r);
     }
@@ -618,14 +635,29 @@ __global__ void __launch_bounds__(256) k_head(HeadArgs a)
 
 extern "C" {
 
+// variant: 0 = heuristic choice; otherwise an explicit kernel (used by the plan's per-layer autotune):
+//   1..4  gather kernel  <BN,WPX> = <64,64> <64,32> <128,64> <128,32>
+//   5..8  resident kernel <BN,WPX> = <64,64> <64,32> <128,64> <128,32>   (stride 1 only)
+int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *weights, const float *bias, void *out,
+                          int ldo, const void *residual, int ldr, int batch, int H, int W, int Cin, int Cout, int ksize,
+                          int stride, int act, int variant, rva_stream_t stream_);
+
 int rva_conv2d_nhwc_f16(rva_ctx *ctx, const void *in, int ldi, const void *weights, const float *bias, void *out,
                         int ldo, const void *residual, int ldr, int batch, int H, int W, int Cin, int Cout, int ksize,
                         int stride, int act, rva_stream_t stream_)
 {
+    return rva_conv2d_nhwc_f16_v(ctx, in, ldi, weights, bias, out, ldo, residual, ldr, batch, H, W, Cin, Cout, ksize, stride,
+                                 act, 0, stream_);
+}
+
+int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *weights, const float *bias, void *out,
+                          int ldo, const void *residual, int ldr, int batch, int H, int W, int Cin, int Cout, int ksize,
+                          int stride, int act, int variant, rva_stream_t stream_)
+{
     if (!ctx) return RVA_ERR_ARG;
     hipStream_t s = (hipStream_t)stream_;
     if (!in || !weights || !bias || !out || batch <= 0 || H <= 0 || W <= 0 || (ksize != 1 && ksize != 3) ||
-        (stride != 1 && stride != 2) || Cin % 8 || Cout % 8 || ldi % 8 || ldo % 8 || (residual && ldr % 8) ||
+        (stride != 1 && stride != 2) || Cin % 8 || Cout % 8 || ldi % 8 || ldo % 8 || (residual && ldr % 8) || variant < 0 || variant > 8 ||
         ((uintptr_t)in | (uintptr_t)out | (uintptr_t)weights | (uintptr_t)residual) % 16)
         return rva_fail(ctx, RVA_ERR_ARG, "rva_conv2d_nhwc_f16: unsupported shape/alignment (Cin%%8, Cout%%8, ld%%8, 16-byte pointers)");
     ConvArgs a{};
@@ -639,16 +671,53 @@ int rva_conv2d_nhwc_f16(rva_ctx *ctx, const void *in, int ldi, const void *weigh
     // tile choice: weights are padded to a multiple of 64 output channels by the caller (rva_conv_cout_pad)
     const int cpad = rva_ceil_div(Cout, 64) * 64;
     const bool bn128 = cpad % 128 == 0;
+    static int num_cus = 0;
+    if (!num_cus) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess) num_cus = prop.multiProcessorCount;
+        if (num_cus <= 0) num_cus = 256;
+    }
+    if (variant) {
+        const int v = (variant - 1) & 3;                      // 0:<64,64> 1:<64,32> 2:<128,64> 3:<128,32>
+        const int vbn = v >= 2 ? 128 : 64, vwpx = (v & 1) ? 32 : 64;
+        if (vbn == 128 && !bn128) return rva_fail(ctx, RVA_ERR_ARG, "variant needs Cout padded to 128");
+        hipError_t ev = hipErrorInvalidValue;
+        if (variant <= 4) {
+            a.n_tiles = cpad / vbn;
+            a.m_tiles = rva_ceil_div(a.M, 4 * vwpx);
+#define RVA_V(BN_, WPX_) (ksize == 1 ? launch_conv<BN_, WPX_, 1>(a, s) : launch_conv<BN_, WPX_, 3>(a, s))
+            ev = v == 0 ? RVA_V(64, 64) : v == 1 ? RVA_V(64, 32) : v == 2 ? RVA_V(128, 64) : RVA_V(128, 32);
+#undef RVA_V
+        } else if (stride == 1) {
+            ResArgs ra{};
+            ra.in = a.in; ra.ldi = ldi; ra.w = a.w; ra.bias = bias; ra.out = a.out; ra.ldo = ldo; ra.res = a.res; ra.ldr = ldr;
+            ra.H = H; ra.W = W; ra.Cin = Cin; ra.CinPad = a.CinPad; ra.Cout = Cout; ra.act = act; ra.M = a.M;
+            ra.n_tiles = cpad / vbn;
+            if (ksize == 3)
+                ev = v == 0 ? launch_res<64, 64, 3, 32, 9>(ra, batch, num_cus, s) : v == 1 ? launch_res<64, 32, 3, 32, 11>(ra, batch, num_cus, s)
+                   : v == 2 ? launch_res<128, 64, 3, 32, 9>(ra, batch, num_cus, s) : launch_res<128, 32, 3, 32, 11>(ra, batch, num_cus, s);
+            else if (a.CinPad % 128 == 0)
+                ev = v == 0 ? launch_res<64, 64, 1, 128, 16>(ra, batch, num_cus, s) : v == 1 ? launch_res<64, 32, 1, 128, 8>(ra, batch, num_cus, s)
+                   : v == 2 ? launch_res<128, 64, 1, 128, 16>(ra, batch, num_cus, s) : hipErrorInvalidValue;
+            else
+                ev = v == 0 ? launch_res<64, 64, 1, 32, 4>(ra, batch, num_cus, s) : v == 1 ? launch_res<64, 32, 1, 32, 2>(ra, batch, num_cus, s)
+                   : hipErrorInvalidValue;
+        }
+        if (ev == hipSuccess) return RVA_OK;
+        (void)hipGetLastError();
+        return rva_fail(ctx, ev == hipErrorInvalidValue ? RVA_ERR_ARG : RVA_ERR_HIP, "conv variant %d not applicable here", variant);
+    }
     if (stride == 1) {
         ResArgs ra{};
         ra.in = a.in; ra.ldi = ldi; ra.w = a.w; ra.bias = bias; ra.out = a.out; ra.ldo = ldo; ra.res = a.res; ra.ldr = ldr;
         ra.H = H; ra.W = W; ra.Cin = Cin; ra.CinPad = a.CinPad; ra.Cout = Cout; ra.act = act; ra.M = a.M;
-        static int num_cus = 0;
-        if (!num_cus) {
-            hipDeviceProp_t prop;
-            if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess) num_cus = prop.multiProcessorCount;
-            if (num_cus <= 0) num_cus = 256;
+        static int dbg = -1, force_bn = 0;
+        if (dbg < 0) {
+            const char *e = getenv("RVA_CONV_DBG"); dbg = e ? atoi(e) : 0;
+            const char *f = getenv("RVA_CONV_BN"); force_bn = f ? atoi(f) : 0;
         }
+        ra.dbg = dbg;
+        const bool bn128 = force_bn == 64 ? false : (cpad % 128 == 0);
         hipError_t e2 = hipErrorInvalidValue;
         if (ksize == 3) {
             // tile = 256 px x 128 ch when that yields enough tiles for every CU, else smaller tiles
@@ -694,8 +763,8 @@ int rva_stem_conv_f16(rva_ctx *ctx, const void *in_planar, const float *weights,
     if (!ctx || !in_planar || !weights || !bias || !out || Cout % 8 || Cout > 64 || ldo % 8)
         return rva_fail(ctx, RVA_ERR_ARG, "rva_stem_conv_f16: bad argument");
     StemArgs a{(const __half *)in_planar, weights, bias, (__half *)out, batch, H, W, (H - 1) / 2 + 1, (W - 1) / 2 + 1, Cout, ldo};
-    const int M = batch * a.Ho * a.Wo;
-    k_stem<<<rva_ceil_div(M, 256), 256, (size_t)Cout * 28 * 4, (hipStream_t)stream_>>>(a);
+    dim3 grid(rva_ceil_div(a.Wo, 32) * rva_ceil_div(a.Ho, 8), batch);
+    k_stem<<<grid, 256, (size_t)Cout * 28 * 4 + 3 * 17 * 66 * 2, (hipStream_t)stream_>>>(a);
     RVA_HIP(ctx, hipGetLastError());
     return RVA_OK;
 }

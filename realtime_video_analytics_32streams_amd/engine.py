@@ -52,7 +52,7 @@ class _View:
 
 class FusedYoloV8:
     def __init__(self, net: YoloV8, batch: int, hw: Tuple[int, int] = (640, 640), device: Optional[torch.device] = None,
-                 ctx: Optional[N.Context] = None):
+                 ctx: Optional[N.Context] = None, autotune: bool = True):
         self.ctx = ctx or ops.context()
         self.dev = device or torch.device("cuda", self.ctx.device)
         self.B, self.H, self.W = batch, hw[0], hw[1]
@@ -62,7 +62,10 @@ class FusedYoloV8:
         self.L = N.lib()
         self._keep: List[torch.Tensor] = []
         self._steps: List[Callable[[C.c_void_p], None]] = []
+        self._tunable = []
         self._build(net)
+        if autotune:
+            self.autotune()
 
     # -- weight preparation ---------------------------------------------------------------------------
     def _conv_params(self, conv: torch.nn.Conv2d):
@@ -92,12 +95,17 @@ class FusedYoloV8:
         assert cin == src.ch and cout == dst.ch, (cin, src.ch, cout, dst.ch)
         B, L, ctx = self.B, self.L, self.ctx
 
-        def run(stream, src=src, dst=dst, res=res):
-            rc = L.rva_conv2d_nhwc_f16(ctx.handle, src.ptr, src.ld, _p(wp), _p(bp), dst.ptr, dst.ld,
-                                       res.ptr if res else None, res.ld if res else 0, B, h, w, cin, cout, k, stride, act,
-                                       stream)
-            ctx.check(rc, "rva_conv2d_nhwc_f16")
+        state = {"variant": 0}
+
+        def launch(stream, variant):
+            return L.rva_conv2d_nhwc_f16_v(ctx.handle, src.ptr, src.ld, _p(wp), _p(bp), dst.ptr, dst.ld,
+                                           res.ptr if res else None, res.ld if res else 0, B, h, w, cin, cout, k, stride, act,
+                                           variant, stream)
+
+        def run(stream):
+            ctx.check(launch(stream, state["variant"]), "rva_conv2d_nhwc_f16")
         self._steps.append(run)
+        self._tunable.append((launch, state, f"{cin}->{cout} k{k}s{stride} {h}x{w}"))
         return (h - 1) // stride + 1 if k == 3 else h // stride, (w - 1) // stride + 1 if k == 3 else w // stride
 
     def _c2f(self, mod: C2f, src: _View, dst: _View, h: int, w: int):
@@ -207,6 +215,36 @@ class FusedYoloV8:
                                               C.c_float(stride), stream), "yolo_head")
             self._steps.append(head)
             a0 += hh * ww
+
+    # -- per-layer kernel selection ---------------------------------------------------------------------
+    def autotune(self, reps: int = 5) -> None:
+        """Time every applicable conv kernel variant on each layer's real shape (buffers hold whatever they
+        hold: timing only) and keep the fastest.  All variants compute the same sums in fp32 with the same
+        per-chunk order of K, so the choice does not change results beyond fp32 summation order."""
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        self.tuning = []
+        cache = {}
+        for launch, state, desc in self._tunable:
+            if desc in cache:
+                state["variant"] = cache[desc][0]
+                continue
+            best = (0, float("inf"))
+            for variant in range(1, 9):
+                if launch(stream, variant) != N.RVA_OK:
+                    continue
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    launch(stream, variant)
+                e1.record()
+                torch.cuda.synchronize()
+                us = e0.elapsed_time(e1) / reps * 1e3
+                if us < best[1]:
+                    best = (variant, us)
+            state["variant"] = best[0]
+            cache[desc] = best
+            self.tuning.append((desc, best[0], round(best[1], 1)))
 
     # -- run ------------------------------------------------------------------------------------------
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
