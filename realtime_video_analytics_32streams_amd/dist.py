@@ -19,10 +19,17 @@ import torch.distributed as dist
 
 
 def init_from_env(backend: Optional[str] = None) -> tuple[int, int, int]:
-    """Read RANK / WORLD_SIZE / LOCAL_RANK (torch.distributed.run contract); returns (rank, world, local)."""
+    """Read RANK / WORLD_SIZE / LOCAL_RANK (torch.distributed.run contract); returns (rank, world, local).
+
+    ``RVA_SHARE_GPU=1`` is a rehearsal mode for boxes with a single GPU: every rank uses device 0 and the
+    process group is gloo (RCCL refuses two ranks on one device); the id exchange is then staged through
+    the host.  It exercises the sharded code path, not RCCL."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("RVA_SHARE_GPU") == "1":
+        local = 0
+        backend = backend or "gloo"
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -55,6 +62,10 @@ class IdSync:
         assert local_counts.numel() == self.per and local_counts.dtype == torch.int32
         if self.world == 1:
             self.buf.copy_(local_counts)
+        elif dist.get_backend(self.group) == "gloo" and self.buf.is_cuda:   # rehearsal mode: stage through the host
+            host = torch.zeros(self.buf.numel(), dtype=torch.int32)
+            dist.all_gather_into_tensor(host, local_counts.cpu().contiguous(), group=self.group)
+            self.buf.copy_(host)
         else:
             dist.all_gather_into_tensor(self.buf, local_counts.contiguous(), group=self.group)
         return self.buf
