@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark = True")
     ap.add_argument("--engine", default="fused", choices=["fused", "torch"],
                     help="detector network: librva fused plan (MFMA conv + fused epilogues) or torch/MIOpen")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="launch every kernel eagerly instead of replaying a captured hipGraph per tick")
     ap.add_argument("--depth", type=int, default=2, choices=[1, 2],
                     help="ticks in flight: 2 = tick k+1 is enqueued before tick k's tracks are consumed (GPU never idles "
                          "on host work); 1 = strictly synchronous ticks (lowest latency)")
@@ -129,6 +131,35 @@ def main():
     for i in range(S):
         slot[pipe.slots[i]] = i
     post_ref = [None]
+    use_graph = (not args.no_graph) and world == 1 and args.engine == "fused"
+
+    def tail(k, tensor, meta, e=None):
+        """Everything after K1: network -> K2/K3 -> K4 -> ids -> D2H snapshot (slot = tick parity)."""
+        with torch.inference_mode():
+            raw = det._infer(tensor)
+            if e: e[2].record()
+            post = det._postprocess_device(raw, [meta])
+            if e: e[3].record()
+        dt.update_from_post(slot, post, dcfg.confidence_threshold)               # K4 (+F1 filter)
+        if id_sync is None:
+            dt.assign_ids()
+        else:
+            dt.assign_ids(id_sync.all_gather_counts(dt.new_counts_tensor()[:S]), pipe.global_index)
+        if e: e[4].record()
+        dt.snapshot_async(k & 1)
+        post_ref[0] = post
+
+    graphs, done = [None, None], [torch.cuda.Event(), torch.cuda.Event()]
+    if use_graph:
+        # the frame ring has two surfaces per stream, the snapshot two slots: one captured graph per tick parity
+        with torch.inference_mode():
+            tensor0, meta0 = det._preprocess([src._ring[0] for src in sources])
+        for par in (0, 1):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                tail(par, tensor0, meta0)
+            graphs[par] = g
+        torch.cuda.synchronize()
 
     def enqueue(k):
         t_enq[k] = time.perf_counter()
@@ -136,23 +167,20 @@ def main():
         e = ev[k]
         with torch.inference_mode():
             e[0].record()
-            tensor, meta = det._preprocess([p.frame for p in packets])           # K1
+            tensor, meta = det._preprocess([p.frame for p in packets])           # K1 (eager, bracketed by events)
             e[1].record()
-            raw = det._infer(tensor)                                              # detector network
-            e[2].record()
-            post = det._postprocess_device(raw, [meta])                           # K2 + K3
-            e[3].record()
-        dt.update_from_post(slot, post, dcfg.confidence_threshold)               # K4 (+F1 filter)
-        if id_sync is None:
-            dt.assign_ids()
+        if use_graph:
+            graphs[k & 1].replay()
+            done[k & 1].record()
         else:
-            dt.assign_ids(id_sync.all_gather_counts(dt.new_counts_tensor()[:S]), pipe.global_index)
-        e[4].record()
-        dt.snapshot_async(k & 1)                                                  # D2H of the track tables
-        post_ref[0] = post
+            tail(k, tensor, meta, e)
 
     def finish(k):
-        tables = dt.snapshot_fetch(k & 1)                                         # tracks visible to the host
+        if use_graph:
+            done[k & 1].synchronize()
+            tables = dt.snapshot_fetch(k & 1, wait=False)
+        else:
+            tables = dt.snapshot_fetch(k & 1)                                     # tracks visible to the host
         lat[k] = time.perf_counter() - t_enq[k]
         return sum(t["n"] for t in tables)
 
@@ -177,8 +205,21 @@ def main():
         elapsed = float(tt.item())
     dets_emitted = int(post.counts.sum().item())
 
-    stage = np.array([[e[i].elapsed_time(e[i + 1]) for i in range(4)] for e in ev])   # ms
-    k1_ms, net_ms, post_ms, trk_ms = stage.mean(0)
+    k1_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))                    # live, every timed tick
+    if use_graph:   # per-stage split of the captured part: eager pass AFTER the timed region (informational)
+        ev2 = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(20)]
+        for k in range(20):
+            packets = [src.next_packet() for src in sources]
+            with torch.inference_mode():
+                ev2[k][0].record()
+                tensor, meta = det._preprocess([p.frame for p in packets])
+                ev2[k][1].record()
+            tail(k, tensor, meta, ev2[k])
+        torch.cuda.synchronize()
+        stage = np.array([[e[i].elapsed_time(e[i + 1]) for i in range(1, 4)] for e in ev2])
+    else:
+        stage = np.array([[e[i].elapsed_time(e[i + 1]) for i in range(1, 4)] for e in ev])
+    net_ms, post_ms, trk_ms = stage.mean(0)
     frames = world * S * K
     fps = frames / elapsed
     k1_gbs = K1_BYTES_PER_FRAME * S / (k1_ms * 1e-3) / 1e9
@@ -200,7 +241,7 @@ def main():
                    "decode": "not measured: " + rocdecode_status()},
         "p99_latency_ms": round(float(np.percentile(lat, 99)) * 1e3, 3),
         "p50_latency_ms": round(float(np.percentile(lat, 50)) * 1e3, 3),
-        "ticks_in_flight": args.depth, "realtime_32x30fps": bool(fps / world >= 30.0 * S and np.percentile(lat, 99) < 1 / 30),
+        "ticks_in_flight": args.depth, "hip_graph": bool(use_graph), "realtime_32x30fps": bool(fps / world >= 30.0 * S and np.percentile(lat, 99) < 1 / 30),
         "stages_ms": {"k1_preprocess": round(float(k1_ms), 4), "detector": round(float(net_ms), 4),
                       "k2k3_postprocess": round(float(post_ms), 4), "k4_tracker": round(float(trk_ms), 4)},
         "detections_per_frame": round(dets_emitted / S, 2), "tracks_per_stream": round(n_tracks / (K * S), 2),

@@ -109,7 +109,7 @@ def lib() -> C.CDLL:
         "rva_tracker_read": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, i32p, _P]),
         "rva_tracker_read_all": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
         "rva_tracker_snapshot_async": (C.c_int, [_P, C.c_int, _P]),
-        "rva_tracker_snapshot_fetch": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
+        "rva_tracker_snapshot_fetch": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
         "rva_tracker_state": (C.c_int, [_P, i64p, C.POINTER(C.c_int), _P]),
         "rva_tracker_set_next_id": (C.c_int, [_P, C.c_int64, _P]),
         "rva_decode_available": (C.c_int, [C.c_char_p, C.c_int]),

@@ -399,15 +399,18 @@ int rva_tracker_snapshot_async(rva_tracker *t, int slot, rva_stream_t stream_)
     const size_t sizes[8] = {sc * 8, sc * 32, sc * 8, sc * 4, sc * 4, sc * 4, sc * 4, (size_t)t->n_streams * 4};
     for (int i = 0; i < 8; ++i)
         RVA_HIP(t->ctx, hipMemcpyAsync(h + snap_off(t, i), src[i], sizes[i], hipMemcpyDeviceToHost, stream));
-    RVA_HIP(t->ctx, hipEventRecord(t->snap_done[slot], stream));
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(stream, &cap);
+    if (cap == hipStreamCaptureStatusNone)   // inside a graph capture the caller synchronises on the replay instead
+        RVA_HIP(t->ctx, hipEventRecord(t->snap_done[slot], stream));
     return RVA_OK;
 }
 
-int rva_tracker_snapshot_fetch(rva_tracker *t, int slot, int64_t *ids, int32_t *cls, int32_t *age, int32_t *hits,
-                               double *conf, double *boxes, int32_t *last_det, int32_t *counts)
+int rva_tracker_snapshot_fetch(rva_tracker *t, int slot, int wait, int64_t *ids, int32_t *cls, int32_t *age,
+                               int32_t *hits, double *conf, double *boxes, int32_t *last_det, int32_t *counts)
 {
     if (!t || slot < 0 || slot > 1) return RVA_ERR_ARG;
-    RVA_HIP(t->ctx, hipEventSynchronize(t->snap_done[slot]));
+    if (wait) RVA_HIP(t->ctx, hipEventSynchronize(t->snap_done[slot]));
     const size_t sc = (size_t)t->n_streams * t->cap;
     const char *h = (const char *)t->h_read[slot];
     if (ids) std::memcpy(ids, h + snap_off(t, 0), sc * 8);
@@ -426,7 +429,7 @@ int rva_tracker_read_all(rva_tracker *t, int64_t *ids, int32_t *cls, int32_t *ag
 {
     int rc = rva_tracker_snapshot_async(t, 0, stream_);
     if (rc != RVA_OK) return rc;
-    return rva_tracker_snapshot_fetch(t, 0, ids, cls, age, hits, conf, boxes, last_det, counts);
+    return rva_tracker_snapshot_fetch(t, 0, 1, ids, cls, age, hits, conf, boxes, last_det, counts);
 }
 
 int rva_tracker_read(rva_tracker *t, int stream_id, int cap, int64_t *ids, int32_t *cls, int32_t *age, int32_t *hits,

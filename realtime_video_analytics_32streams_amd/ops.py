@@ -298,12 +298,12 @@ class DeviceTracker:
     def snapshot_async(self, slot: int) -> None:
         self.ctx.check(N.lib().rva_tracker_snapshot_async(self.handle, slot, _stream_ptr()), "rva_tracker_snapshot_async")
 
-    def snapshot_fetch(self, slot: int) -> List[dict]:
+    def snapshot_fetch(self, slot: int, wait: bool = True) -> List[dict]:
         S, cap = self.n_streams, self.capacity
         ids = np.empty((S, cap), np.int64); cls = np.empty((S, cap), np.int32); age = np.empty((S, cap), np.int32)
         hits = np.empty((S, cap), np.int32); conf = np.empty((S, cap), np.float64); box = np.empty((S, cap, 4), np.float64)
         cnt = np.empty(S, np.int32); ld = np.empty((S, cap), np.int32)
-        rc = N.lib().rva_tracker_snapshot_fetch(self.handle, slot, C.c_void_p(ids.ctypes.data), C.c_void_p(cls.ctypes.data),
+        rc = N.lib().rva_tracker_snapshot_fetch(self.handle, slot, 1 if wait else 0, C.c_void_p(ids.ctypes.data), C.c_void_p(cls.ctypes.data),
                                                 C.c_void_p(age.ctypes.data), C.c_void_p(hits.ctypes.data),
                                                 C.c_void_p(conf.ctypes.data), C.c_void_p(box.ctypes.data),
                                                 C.c_void_p(ld.ctypes.data), C.c_void_p(cnt.ctypes.data))
