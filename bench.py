@@ -223,6 +223,12 @@ def main():
     frames = world * S * K
     fps = frames / elapsed
     k1_gbs = K1_BYTES_PER_FRAME * S / (k1_ms * 1e-3) / 1e9
+    # HBM traffic of the K1 launch from rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see the file): a
+    # committed measurement of exactly this launch shape, not something bench.py can collect while timing
+    k1_traffic = None
+    pmc = ROOT / "profiles" / "r01_k1_pmc.json"
+    if pmc.exists() and S == 32 and (args.width, args.height) == (1920, 1080):
+        k1_traffic = json.loads(pmc.read_text())["traffic_bytes_per_launch"]
     net_tflops = 2 * macs * S / (net_ms * 1e-3) / 1e12
 
     out = {
@@ -248,7 +254,8 @@ def main():
         "detector_tflops": round(net_tflops, 2), "detector_frac_of_mfma_peak": round(net_tflops / MFMA_PEAK_TFLOPS, 4),
         "roofline": {"kernel": "k1_ratio<3,half> (NV12 1080p -> fp16 3x640x640, one launch per tick)", "bound": "hbm",
                      "achieved": round(k1_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(k1_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                     "frac": round(k1_gbs / HBM_PEAK_GBS, 4), "traffic": k1_traffic,
+                     "traffic_source": "profiles/r01_k1_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" if k1_traffic else None,
                      "algorithmic_bytes_per_launch": K1_BYTES_PER_FRAME * S, "avg_launch_us": round(float(k1_ms) * 1e3, 2)},
     }
     if rank == 0 and not args.no_cpu_baseline:

@@ -20,6 +20,8 @@
 //                 the tap tables (host-computed exactly like OpenCV, cached on the device).
 #include <hip/hip_fp16.h>
 
+#include <cstdlib>
+
 #include "rva_internal.h"
 
 namespace {
@@ -82,46 +84,55 @@ __device__ __forceinline__ void store8(OutT *dst, const OutT *v, bool vec_ok, in
 }
 
 // ---- integer-ratio fast path -----------------------------------------------------------------
-template <int R, typename OutT>
+template <int R, typename OutT, int PX>
 __global__ void __launch_bounds__(256) k1_ratio(K1Args a)
 {
     const int img = blockIdx.y;
-    const int groups = a.dst_w >> 3;
+    const int groups = a.dst_w / PX;
     const int item = blockIdx.x * 256 + threadIdx.x;
     if (item >= groups * a.dst_h) return;
     const int oy = item / groups, xg = item - oy * groups;
-    const int ox = xg << 3;
+    const int ox = xg * PX;
     const size_t plane = (size_t)a.dst_w * a.dst_h;
     OutT *out = (OutT *)a.out + (size_t)img * 3 * plane + (size_t)oy * a.dst_w + ox;
-    alignas(16) OutT vr[8], vg[8], vb[8];
+    alignas(16) OutT vr[PX], vg[PX], vb[PX];
     const int cy = oy - a.top, cx = ox - a.left;
     if (cy < 0 || cy >= a.new_h || cx < 0 || cx >= a.new_w) {  // letterbox border (detector.py:233-241)
         const OutT p = norm_yolo(114, OutT());
 #pragma unroll
-        for (int i = 0; i < 8; ++i) vr[i] = vg[i] = vb[i] = p;
+        for (int i = 0; i < PX; ++i) vr[i] = vg[i] = vb[i] = p;
     } else {
         const uint8_t *yp = a.p0[img];
         const uint8_t *uvp = a.p1[img];
         const int pitch = a.pitch[img];
-        constexpr int NW = R;          // 8-byte words per 8 output pixels
+        constexpr int NW = R * PX / 8; // 8-byte words per PX output pixels
         constexpr bool ODD = (R & 1) != 0;
         constexpr int ROWS = ODD ? 1 : 2;
         const int sy0 = ODD ? R * cy + (R - 1) / 2 : R * cy + R / 2 - 1;
-        const size_t xoff = (size_t)R * cx;  // multiple of 8
+        const size_t xoff = (size_t)R * cx;  // multiple of PX
         uint2 yw[ROWS][NW], uw[ROWS][NW];
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) {
             const uint2 *ys = reinterpret_cast<const uint2 *>(yp + (size_t)(sy0 + r) * pitch + xoff);
             const uint2 *us = reinterpret_cast<const uint2 *>(uvp + (size_t)((sy0 + r) >> 1) * pitch + xoff);
+            if constexpr (PX == 16) {   // 16-byte loads (two words each)
 #pragma unroll
-            for (int k = 0; k < NW; ++k) { yw[r][k] = ys[k]; uw[r][k] = us[k]; }
+                for (int k = 0; k < NW; k += 2) {
+                    const uint4 y4 = *reinterpret_cast<const uint4 *>(ys + k), u4v = *reinterpret_cast<const uint4 *>(us + k);
+                    yw[r][k] = make_uint2(y4.x, y4.y); yw[r][k + 1] = make_uint2(y4.z, y4.w);
+                    uw[r][k] = make_uint2(u4v.x, u4v.y); uw[r][k + 1] = make_uint2(u4v.z, u4v.w);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < NW; ++k) { yw[r][k] = ys[k]; uw[r][k] = us[k]; }
+            }
         }
         auto byte_at = [](const uint2 *w, int o) -> int {
             const uint32_t d = (o & 4) ? w[o >> 3].y : w[o >> 3].x;
             return (int)((d >> ((o & 3) * 8)) & 0xffu);
         };
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < PX; ++i) {
             int b, g, r;
             if constexpr (ODD) {
                 const int o = R * i + (R - 1) / 2;
@@ -144,9 +155,12 @@ __global__ void __launch_bounds__(256) k1_ratio(K1Args a)
             vr[i] = norm_yolo(r, OutT()); vg[i] = norm_yolo(g, OutT()); vb[i] = norm_yolo(b, OutT());
         }
     }
-    store8<OutT>(out, vr, true, 8);              // R plane first (BGR2RGB, detector.py:245)
-    store8<OutT>(out + plane, vg, true, 8);
-    store8<OutT>(out + 2 * plane, vb, true, 8);
+#pragma unroll
+    for (int h = 0; h < PX; h += 8) {
+        store8<OutT>(out + h, vr + h, true, 8);              // R plane first (BGR2RGB, detector.py:245)
+        store8<OutT>(out + plane + h, vg + h, true, 8);
+        store8<OutT>(out + 2 * plane + h, vb + h, true, 8);
+    }
 }
 
 // ---- general path ----------------------------------------------------------------------------
@@ -219,15 +233,15 @@ __global__ void __launch_bounds__(256) k1_generic(K1Args a)
     store8<OutT>(out + 2 * plane, vb, vec_ok, nvalid);
 }
 
-template <typename OutT>
+template <typename OutT, int PX>
 bool launch_ratio(int R, dim3 grid, hipStream_t s, const K1Args &a)
 {
     switch (R) {
-        case 1: k1_ratio<1, OutT><<<grid, 256, 0, s>>>(a); return true;
-        case 2: k1_ratio<2, OutT><<<grid, 256, 0, s>>>(a); return true;
-        case 3: k1_ratio<3, OutT><<<grid, 256, 0, s>>>(a); return true;
-        case 4: k1_ratio<4, OutT><<<grid, 256, 0, s>>>(a); return true;
-        case 6: k1_ratio<6, OutT><<<grid, 256, 0, s>>>(a); return true;
+        case 1: k1_ratio<1, OutT, PX><<<grid, 256, 0, s>>>(a); return true;
+        case 2: k1_ratio<2, OutT, PX><<<grid, 256, 0, s>>>(a); return true;
+        case 3: k1_ratio<3, OutT, PX><<<grid, 256, 0, s>>>(a); return true;
+        case 4: k1_ratio<4, OutT, PX><<<grid, 256, 0, s>>>(a); return true;
+        case 6: k1_ratio<6, OutT, PX><<<grid, 256, 0, s>>>(a); return true;
         default: return false;
     }
 }
@@ -273,8 +287,18 @@ int preprocess_common(rva_ctx *ctx, bool nv12, bool clip, const void *const *p0,
     const bool ratio_ok = nv12 && !clip && aligned8 && out_aligned && R * m.new_w == src_w && R * m.new_h == src_h &&
                           (dst_w % 8 == 0) && (m.new_w % 8 == 0) && (m.pad_left % 8 == 0);
     if (ratio_ok) {
-        dim3 grid(rva_ceil_div((dst_w / 8) * dst_h, 256), n);
-        const bool ok = out_dtype == RVA_F16 ? launch_ratio<__half>(R, grid, stream, a) : launch_ratio<float>(R, grid, stream, a);
+        // 16 pixels per lane (16-byte loads) when the geometry is 16-aligned and every surface 16-byte aligned
+        static int px_env = -1;
+        if (px_env < 0) { const char *e = getenv("RVA_K1_PX"); px_env = e ? atoi(e) : 0; }
+        bool aligned16 = true;
+        for (int i = 0; i < n; ++i)
+            aligned16 = aligned16 && ((uintptr_t)p0[i] % 16 == 0) && ((uintptr_t)p1[i] % 16 == 0) && pitches[i] % 16 == 0;
+        const bool px16 = px_env == 16 && aligned16   /* measured slower than 8 px/lane (profiles/r01_k1_variants.txt): opt-in only */ && dst_w % 16 == 0 && m.new_w % 16 == 0 && m.pad_left % 16 == 0 && R <= 3 &&
+                          out_dtype == RVA_F16;
+        const int PXv = px16 ? 16 : 8;
+        dim3 grid(rva_ceil_div((dst_w / PXv) * dst_h, 256), n);
+        const bool ok = px16 ? launch_ratio<__half, 16>(R, grid, stream, a)
+                             : (out_dtype == RVA_F16 ? launch_ratio<__half, 8>(R, grid, stream, a) : launch_ratio<float, 8>(R, grid, stream, a));
         if (ok) {
             RVA_HIP(ctx, hipGetLastError());
             return RVA_OK;
