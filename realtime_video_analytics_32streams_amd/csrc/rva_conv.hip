@@ -491,16 +491,14 @@ struct StemArgs {
     int B, H, W, Ho, Wo, Cout, ldo;
 };
 
-__global__ void __launch_bounds__(256) k_stem(StemArgs a)
+__global__ void __launch_bounds__(256) k_stem(StemArgs a, const float *__restrict__ gw, const float *__restrict__ gb)
 {
     // block = 8 x 32 output pixels of one image; the 17 x 65 x 3 input patch is staged in LDS with
-    // coalesced row loads, weights/bias sit in LDS too (broadcast reads)
+    // coalesced row loads.  Weights are wave-uniform: read through the scalar unit (s_load from the
+    // kernel-argument pointers) so the 864 FMAs per pixel take their multiplier from SGPRs, not LDS.
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float *sw = (float *)smem;                               // [Cout][28]
-    __half *tile = (__half *)(sw + a.Cout * 28);             // [3][17][66]
+    __half *tile = (__half *)smem;                           // [3][17][66]
     const int tid = threadIdx.x;
-    for (int i = tid; i < a.Cout * 27; i += 256) sw[(i / 27) * 28 + i % 27] = a.w[i];
-    for (int i = tid; i < a.Cout; i += 256) sw[i * 28 + 27] = a.bias[i];
     const int tiles_x = (a.Wo + 31) >> 5;
     const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, b = blockIdx.y;
     const int ox0 = tx * 32, oy0 = ty * 8;
@@ -524,12 +522,13 @@ __global__ void __launch_bounds__(256) k_stem(StemArgs a)
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) x[c * 9 + ky * 3 + kx] = __half2float(tile[(c * 17 + ly * 2 + ky) * 66 + lx * 2 + kx]);
     __half *o = a.out + ((size_t)(b * a.Ho + oy) * a.Wo + ox) * a.ldo;
+#pragma unroll 1
     for (int co = 0; co < a.Cout; co += 8) {
         alignas(16) __half r[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const float *wr = sw + (co + u) * 28;
-            float sacc = wr[27];
+            const float *wr = gw + (co + u) * 27;            // uniform address -> scalar loads
+            float sacc = gb[co + u];
 #pragma unroll
             for (int k = 0; k < 27; ++k) sacc = fmaf(wr[k], x[k], sacc);
             r[u] = __float2half_rn(silu_f(sacc));
@@ -764,7 +763,7 @@ int rva_stem_conv_f16(rva_ctx *ctx, const void *in_planar, const float *weights,
         return rva_fail(ctx, RVA_ERR_ARG, "rva_stem_conv_f16: bad argument");
     StemArgs a{(const __half *)in_planar, weights, bias, (__half *)out, batch, H, W, (H - 1) / 2 + 1, (W - 1) / 2 + 1, Cout, ldo};
     dim3 grid(rva_ceil_div(a.Wo, 32) * rva_ceil_div(a.Ho, 8), batch);
-    k_stem<<<grid, 256, (size_t)Cout * 28 * 4 + 3 * 17 * 66 * 2, (hipStream_t)stream_>>>(a);
+    k_stem<<<grid, 256, (size_t)3 * 17 * 66 * 2, (hipStream_t)stream_>>>(a, weights, bias);
     RVA_HIP(ctx, hipGetLastError());
     return RVA_OK;
 }

@@ -141,6 +141,8 @@ __global__ void __launch_bounds__(K3_THREADS) k3_nms(K3Args a)
     float4 *kept_box = (float4 *)(k3_smem + (size_t)a.kcap * 8);        // [64]
     int *s_ctl = (int *)(k3_smem + (size_t)a.kcap * 8 + 64 * 16);       // [0]=kept in chunk, [1]=out count
     unsigned char *removed = k3_smem + (size_t)a.kcap * 8 + 64 * 16 + 16;  // [kcap]
+    int *wprefix = (int *)(k3_smem + (((size_t)a.kcap * 9 + 64 * 16 + 16 + 15) & ~(size_t)15));  // [nwords] passing anchors before word w
+    int *wave_tot = wprefix + a.nwords;                                  // [K3_THREADS/64] (all LDS is dynamic: keeps the base 16-byte aligned)
 
     int K = a.count[b];
     if (a.out_ncand && tid == 0) a.out_ncand[b] = K;
@@ -168,19 +170,67 @@ __global__ void __launch_bounds__(K3_THREADS) k3_nms(K3Args a)
         keys[i] = k;
         removed[i] = 0;
     }
-    if (tid == 0) { s_ctl[0] = 0; s_ctl[1] = 0; }
+    if (tid == 0) { s_ctl[0] = 0; s_ctl[1] = 0; s_ctl[2] = 0; }
     __syncthreads();
-    for (int k = 2; k <= Kpad; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < Kpad; i += K3_THREADS) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const unsigned long long x = keys[i], y = keys[ixj];
-                    const bool up = (i & k) == 0;
-                    if ((x > y) == up) { keys[i] = y; keys[ixj] = x; }
-                }
+    // prefix popcounts of the pass bitmap (for the `keep` index of each survivor), all threads cooperate
+    if (a.out_cand) {
+        const uint32_t *bw = a.bits + (long)b * a.nwords;
+        for (int w0 = 0; w0 < a.nwords; w0 += K3_THREADS) {   // block-wide exclusive scan, 512 words per round
+            const int w = w0 + tid;
+            const int c = w < a.nwords ? __popc(bw[w]) : 0;
+            int incl = c;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int o = __shfl_up(incl, off);
+                if (lane >= off) incl += o;
             }
+            if (lane == 63) wave_tot[wave] = incl;
             __syncthreads();
+            int base = w0 ? wprefix[w0 - 1] + s_ctl[2] : 0;   // carry of the previous round
+            for (int q = 0; q < wave; ++q) base += wave_tot[q];
+            if (w < a.nwords) wprefix[w] = base + incl - c;
+            __syncthreads();
+            if (tid == K3_THREADS - 1) s_ctl[2] = c;           // popcount of the round's last word (prefix is exclusive)
+            __syncthreads();
+        }
+    }
+    if (Kpad <= K3_THREADS) {
+        // one key per thread: partner exchange by wave shuffle while the stride stays inside a wave (j < 64),
+        // through LDS only for the few wider strides -> a handful of block barriers instead of one per stage
+        unsigned long long key = tid < Kpad ? keys[tid] : ~0ull;
+        for (int k = 2; k <= Kpad; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                unsigned long long other;
+                if (j >= 64) {
+                    __syncthreads();
+                    if (tid < Kpad) keys[tid] = key;
+                    __syncthreads();
+                    other = tid < Kpad ? keys[tid ^ j] : ~0ull;
+                } else {
+                    const unsigned lo = __shfl_xor((unsigned)key, j), hi = __shfl_xor((unsigned)(key >> 32), j);
+                    other = ((unsigned long long)hi << 32) | lo;
+                }
+                const bool up = (tid & k) == 0, lower = (tid & j) == 0;
+                const unsigned long long mn = key < other ? key : other, mx = key < other ? other : key;
+                key = (lower == up) ? mn : mx;
+            }
+        }
+        __syncthreads();
+        if (tid < Kpad) keys[tid] = key;
+        __syncthreads();
+    } else {
+        for (int k = 2; k <= Kpad; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = tid; i < Kpad; i += K3_THREADS) {
+                    const int ixj = i ^ j;
+                    if (ixj > i) {
+                        const unsigned long long x = keys[i], y = keys[ixj];
+                        const bool up = (i & k) == 0;
+                        if ((x > y) == up) { keys[i] = y; keys[ixj] = x; }
+                    }
+                }
+                __syncthreads();
+            }
         }
     }
     const int nchunks = (K + 63) >> 6;
@@ -213,12 +263,8 @@ __global__ void __launch_bounds__(K3_THREADS) k3_nms(K3Args a)
                     a.out_cls[o] = a.sp_cls[(long)b * a.A + an];
                     if (a.out_anchor) a.out_anchor[o] = an;
                     if (a.out_cand) {  // index among the thresholded candidates in anchor order
-                        const uint32_t *bw = a.bits + (long)b * a.nwords;
-                        int cnt = 0;
                         const int w = an >> 5;
-                        for (int q = 0; q < w; ++q) cnt += __popc(bw[q]);
-                        cnt += __popc(bw[w] & ((1u << (an & 31)) - 1u));
-                        a.out_cand[o] = cnt;
+                        a.out_cand[o] = wprefix[w] + __popc(a.bits[(long)b * a.nwords + w] & ((1u << (an & 31)) - 1u));
                     }
                 } else {
                     atomicOr(a.flags, 1);
@@ -280,13 +326,13 @@ extern "C" int rva_postprocess_batch(rva_ctx *ctx, const void *raw, int raw_dtyp
 
     int kcap = 64;
     while (kcap < A && kcap < 16384) kcap <<= 1;
-    const size_t smem = (size_t)kcap * 8 + 64 * 16 + 16 + (size_t)kcap;
+    const int nwords = rva_ceil_div(A, 32);
+    const size_t smem = (((size_t)kcap * 9 + 64 * 16 + 16 + 15) & ~(size_t)15) + (size_t)nwords * 4 + 64;
     static size_t smem_set = 0;
     if (smem > smem_set) {
         RVA_HIP(ctx, hipFuncSetAttribute((const void *)k3_nms, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         smem_set = smem;
     }
-    const int nwords = rva_ceil_div(A, 32);
 
     for (int b0 = 0; b0 < batch; b0 += RVA_MAX_BATCH) {
         const int nb = batch - b0 < RVA_MAX_BATCH ? batch - b0 : RVA_MAX_BATCH;
