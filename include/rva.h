@@ -203,7 +203,8 @@ int rva_tracker_set_next_id(rva_tracker *trk, int64_t next_id, rva_stream_t stre
  *   with CinPad = Cin rounded up to 32 (padding rows / channels zero), bias: float32 [rva_conv_cout_pad(Cout)].
  *   MFMA implicit GEMM, fp32 accumulate.
  * rva_stem_conv_f16: first layer, 3x3 stride 2 on the PLANAR tensor K1 writes ([batch,3,H,W]);
- *   weights float32 [Cout][27] in (c,ky,kx) order; output NHWC.
+ *   weights float16 [64][32]: row = output channel (zero beyond Cout); column order with j = c*3 + ky:
+ *   k = 2*j + kx for kx in {0,1}, k = 18 + j for kx = 2, zero for k >= 27; bias float32 [64]; Cout <= 64; NHWC out.
  * rva_maxpool5_nhwc_f16 / rva_upsample2x_nhwc_f16: SPPF pooling, FPN nearest upsample, on channel slices.
  * rva_yolo_head_f16: DFL expectation + dist2bbox + sigmoid of one pyramid level into
  *   out[batch, 4+nc, anchors_total] at anchor_offset -- the `[B,84,8400]` tensor rva_postprocess_batch reads.
@@ -217,7 +218,7 @@ int rva_conv2d_nhwc_f16(rva_ctx *ctx, const void *in, int ldi, const void *weigh
 int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *weights, const float *bias,
                           void *out, int ldo, const void *residual, int ldr, int batch, int H, int W, int Cin,
                           int Cout, int ksize, int stride, int act, int variant, rva_stream_t stream);
-int rva_stem_conv_f16(rva_ctx *ctx, const void *in_planar, const float *weights, const float *bias,
+int rva_stem_conv_f16(rva_ctx *ctx, const void *in_planar, const void *weights, const float *bias,
                       void *out, int ldo, int batch, int H, int W, int Cout, rva_stream_t stream);
 int rva_maxpool5_nhwc_f16(rva_ctx *ctx, const void *in, int ldi, void *out, int ldo, int batch, int H,
                           int W, int C, rva_stream_t stream);

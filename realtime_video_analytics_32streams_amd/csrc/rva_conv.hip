@@ -51,7 +51,9 @@ struct ConvArgs {
 
 constexpr int LDSROW = 40;  // halfs per staged row: 32 data + 8 pad (80 B) -> conflict-free b128 reads
 
-__device__ __forceinline__ float silu_f(float v) { return __fdividef(v, 1.0f + __expf(-v)); }
+// x * sigmoid(x) with v_exp_f32 + v_rcp_f32 (1 ulp): __fdividef / operator/ expand to the ~12-instruction IEEE
+// division sequence here, which dominated the epilogues (64-128 SiLUs per thread per tile)
+__device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
 template <int BN, int WPX, int KS>
 __global__ void __launch_bounds__(256) k_conv_mfma(ConvArgs a)
@@ -489,51 +491,138 @@ hipError_t launch_res(ResArgs &a, int batch, int num_cus, hipStream_t s)
 struct StemArgs {
     const __half *in; const float *w; const float *bias; __half *out;   // w: [Cout][27] (c, ky, kx)
     int B, H, W, Ho, Wo, Cout, ldo;
+    int dbg;
 };
 
-__global__ void __launch_bounds__(256) k_stem(StemArgs a, const float *__restrict__ gw, const float *__restrict__ gb)
+__global__ void __launch_bounds__(256) k_stem(StemArgs a, const __half *__restrict__ gw, const float *__restrict__ gb)
 {
-    // block = 8 x 32 output pixels of one image; the 17 x 65 x 3 input patch is staged in LDS with
-    // coalesced row loads.  Weights are wave-uniform: read through the scalar unit (s_load from the
-    // kernel-argument pointers) so the 864 FMAs per pixel take their multiplier from SGPRs, not LDS.
+    // Persistent blocks; a tile = 8 x 32 output pixels of one image.  Per tile: the 17 x 65 x 3 input patch
+    // (prefetched into registers while the previous tile computes) is staged in LDS, each thread writes its
+    // pixel's 27 taps (padded to K = 32) as one im2col row, and the 27-deep dot products run as ONE
+    // v_mfma_f32_16x16x32_f16 step per 16x16 output block (weights = A operand, loaded once per block;
+    // pixels = B operand).  A VALU formulation needs 864 FMAs per pixel and saturated the scalar unit.
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __half *tile = (__half *)smem;                           // [3][17][66]
-    const int tid = threadIdx.x;
-    const int tiles_x = (a.Wo + 31) >> 5;
-    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, b = blockIdx.y;
-    const int ox0 = tx * 32, oy0 = ty * 8;
-    const int ix0 = ox0 * 2 - 1, iy0 = oy0 * 2 - 1;
-    for (int i = tid; i < 3 * 17 * 65; i += 256) {
-        const int c = i / (17 * 65), r = (i / 65) % 17, x = i % 65;
-        const int iy = iy0 + r, ix = ix0 + x;
-        __half v = __float2half(0.f);
-        if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) v = a.in[((size_t)(b * 3 + c) * a.H + iy) * a.W + ix];
-        tile[(c * 17 + r) * 66 + x] = v;
+    __half *tile = (__half *)smem;                                              // [3][17][66]
+    __half *col = (__half *)(smem + ((3 * 17 * 66 * 2 + 15) & ~15));            // [256][LDSROW] im2col rows / output stage
+    __half *wl = col + 256 * (a.Cout + 8 > LDSROW ? a.Cout + 8 : LDSROW);       // [64][LDSROW] weights (fp16, K padded)
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tiles_x = (a.Wo + 31) >> 5, tiles_y = (a.Ho + 7) >> 3;
+    const int tiles_img = tiles_x * tiles_y, total = tiles_img * a.B;
+    {   // packed fp16 weights [64][32]: one 16-byte load per thread, once per block
+        const u4 wv4 = *reinterpret_cast<const u4 *>(gw + tid * 8);
+        *reinterpret_cast<u4 *>(wl + (size_t)(tid >> 2) * LDSROW + (tid & 3) * 8) = wv4;
     }
-    __syncthreads();
-    const int lx = tid & 31, ly = tid >> 5;
-    const int ox = ox0 + lx, oy = oy0 + ly;
-    if (ox >= a.Wo || oy >= a.Ho) return;
-    float x[27];
+    const int nblk = (a.Cout + 15) >> 4;                   // 16-channel blocks (<= 4)
+    float bv[4][4];
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) x[c * 9 + ky * 3 + kx] = __half2float(tile[(c * 17 + ly * 2 + ky) * 66 + lx * 2 + kx]);
-    __half *o = a.out + ((size_t)(b * a.Ho + oy) * a.Wo + ox) * a.ldo;
-#pragma unroll 1
-    for (int co = 0; co < a.Cout; co += 8) {
-        alignas(16) __half r[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const float *wr = gw + (co + u) * 27;            // uniform address -> scalar loads
-            float sacc = gb[co + u];
-#pragma unroll
-            for (int k = 0; k < 27; ++k) sacc = fmaf(wr[k], x[k], sacc);
-            r[u] = __float2half_rn(silu_f(sacc));
+        for (int u = 0; u < 4; ++u) {
+            const int co = 16 * i + (lane >> 4) * 4 + u;
+            bv[i][u] = co < a.Cout ? gb[co] : 0.f;
         }
-        *reinterpret_cast<uint4 *>(o + co) = *reinterpret_cast<const uint4 *>(r);
+    constexpr int NR = 13;                                 // ceil(51 patch rows / 4 waves)
+    unsigned short v0[NR], v1[NR];
+    const bool has_x1 = lane == 0;                         // lane 0 also fetches column 64
+    auto prefetch = [&](int t) {                           // lanes walk along x: no div/mod per element
+        const int bb = t / tiles_img, r2 = t - bb * tiles_img, tyy = r2 / tiles_x, txx = r2 - tyy * tiles_x;
+        const int ix0 = txx * 64 - 1, iy0 = tyy * 16 - 1;
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            const int row = wv + 4 * k;                    // 0..50
+            const int c = row / 17, r = row - c * 17;
+            const int iy = iy0 + r, ix = ix0 + lane;
+            v0[k] = 0; v1[k] = 0;
+            if (!(a.dbg & 1) && row < 51 && (unsigned)iy < (unsigned)a.H) {
+                const unsigned short *src = reinterpret_cast<const unsigned short *>(a.in) + ((size_t)(bb * 3 + c) * a.H + iy) * a.W;
+                if ((unsigned)ix < (unsigned)a.W) v0[k] = src[ix];
+                if (has_x1 && (unsigned)(ix0 + 64) < (unsigned)a.W) v1[k] = src[ix0 + 64];
+            }
+        }
+    };
+    int t = blockIdx.x;
+    if (t < total) prefetch(t);
+    for (; t < total; t += gridDim.x) {
+        const int b = t / tiles_img, r2 = t - b * tiles_img, ty = r2 / tiles_x, tx = r2 - ty * tiles_x;
+        const int ox0 = tx * 32, oy0 = ty * 8;
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            const int row = wv + 4 * k;
+            if (row < 51) {
+                unsigned short *dst = reinterpret_cast<unsigned short *>(tile) + row * 66;
+                dst[lane] = v0[k];
+                if (has_x1) dst[64] = v1[k];
+            }
+        }
+        __syncthreads();
+        if (t + (int)gridDim.x < total) prefetch(t + gridDim.x);   // next tile's patch flies under this tile's work
+        {   // im2col row of this thread's pixel.  K order (shared with the host-packed weights):
+            //   k = 2*j + kx for kx in {0,1}  (j = c*3 + ky): the two halfs are one aligned dword of the patch row,
+            //   k = 18 + j   for kx = 2, k = 27..31 zero.
+            const int lx = tid & 31, ly = tid >> 5;
+            uint32_t d[16];
+            unsigned short sgl[9];
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                const __half *p = tile + ((j / 3) * 17 + ly * 2 + (j % 3)) * 66 + lx * 2;
+                d[j] = *reinterpret_cast<const uint32_t *>(p);                 // kx = 0, 1
+                sgl[j] = *reinterpret_cast<const unsigned short *>(p + 2);     // kx = 2
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d[9 + j] = (uint32_t)sgl[2 * j] | ((uint32_t)sgl[2 * j + 1] << 16);
+            d[13] = sgl[8];
+            d[14] = 0; d[15] = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<u4 *>(col + (size_t)tid * LDSROW + q * 8) = u4{d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]};
+        }
+        __syncthreads();
+        f4 acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+        h8 bf[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const h8 *>(col + (size_t)(wv * 64 + 16 * j + (lane & 15)) * LDSROW + (lane >> 4) * 8);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i < nblk) {
+                const h8 af = *reinterpret_cast<const h8 *>(wl + (size_t)(16 * i + (lane & 15)) * LDSROW + (lane >> 4) * 8);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        __syncthreads();                                    // im2col rows are dead: reuse them as the output stage
+        const int srow = a.Cout + 8;
+        __half *stage = col;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i < nblk) {
+                const int co = 16 * i + (lane >> 4) * 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int px = wv * 64 + 16 * j + (lane & 15);
+                    __half2 lo = __floats2half2_rn(silu_f(acc[i][j][0] + bv[i][0]), silu_f(acc[i][j][1] + bv[i][1]));
+                    __half2 hi = __floats2half2_rn(silu_f(acc[i][j][2] + bv[i][2]), silu_f(acc[i][j][3] + bv[i][3]));
+                    uint2 pk;
+                    pk.x = *reinterpret_cast<uint32_t *>(&lo);
+                    pk.y = *reinterpret_cast<uint32_t *>(&hi);
+                    if (co < a.Cout) *reinterpret_cast<uint2 *>(stage + (size_t)px * srow + co) = pk;
+                }
+            }
+        }
+        __syncthreads();
+        const int cpr = a.Cout >> 3;
+        for (int q = tid; q < 256 * cpr; q += 256) {
+            const int px = q / cpr, pc = q - px * cpr;
+            const int ox = ox0 + (px & 31), oy = oy0 + (px >> 5);
+            if (ox < a.Wo && oy < a.Ho && !(a.dbg & 4))
+                *reinterpret_cast<uint4 *>(a.out + ((size_t)(b * a.Ho + oy) * a.Wo + ox) * a.ldo + pc * 8) =
+                    *reinterpret_cast<const uint4 *>(stage + (size_t)px * srow + pc * 8);
+        }
+        // the next iteration's first barrier (after the tile fill) also orders these stage reads before the
+        // next im2col writes; the tile buffer itself is not touched by the output copy
     }
 }
 
@@ -624,8 +713,8 @@ __global__ void __launch_bounds__(256) k_head(HeadArgs a)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const float2 f = __half22float2(hq[t]);
-            o[(size_t)(4 + c + 2 * t) * a.A] = __float2half_rn(1.0f / (1.0f + __expf(-f.x)));
-            o[(size_t)(5 + c + 2 * t) * a.A] = __float2half_rn(1.0f / (1.0f + __expf(-f.y)));
+            o[(size_t)(4 + c + 2 * t) * a.A] = __float2half_rn(__builtin_amdgcn_rcpf(1.0f + __expf(-f.x)));
+            o[(size_t)(5 + c + 2 * t) * a.A] = __float2half_rn(__builtin_amdgcn_rcpf(1.0f + __expf(-f.y)));
         }
     }
 }
@@ -756,14 +845,17 @@ int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *wei
 
 int rva_conv_cout_pad(int Cout) { return rva_ceil_div(Cout, 64) * 64; }
 
-int rva_stem_conv_f16(rva_ctx *ctx, const void *in_planar, const float *weights, const float *bias, void *out, int ldo,
+int rva_stem_conv_f16(rva_ctx *ctx, const void *in_planar, const void *weights, const float *bias, void *out, int ldo,
                       int batch, int H, int W, int Cout, rva_stream_t stream_)
 {
     if (!ctx || !in_planar || !weights || !bias || !out || Cout % 8 || Cout > 64 || ldo % 8)
         return rva_fail(ctx, RVA_ERR_ARG, "rva_stem_conv_f16: bad argument");
-    StemArgs a{(const __half *)in_planar, weights, bias, (__half *)out, batch, H, W, (H - 1) / 2 + 1, (W - 1) / 2 + 1, Cout, ldo};
-    dim3 grid(rva_ceil_div(a.Wo, 32) * rva_ceil_div(a.Ho, 8), batch);
-    k_stem<<<grid, 256, (size_t)3 * 17 * 66 * 2, (hipStream_t)stream_>>>(a, weights, bias);
+    StemArgs a{(const __half *)in_planar, nullptr, bias, (__half *)out, batch, H, W, (H - 1) / 2 + 1, (W - 1) / 2 + 1, Cout, ldo, 0};
+    { const char *e = getenv("RVA_STEM_DBG"); a.dbg = e ? atoi(e) : 0; }
+    const int total_tiles = rva_ceil_div(a.Wo, 32) * rva_ceil_div(a.Ho, 8) * batch;
+    int grid = 256 * 4;                                     // persistent: ~4 blocks per CU (LDS-limited)
+    if (grid > total_tiles) grid = total_tiles;
+    k_stem<<<grid, 256, (size_t)((3 * 17 * 66 * 2 + 15) & ~15) + (size_t)(256 * (Cout + 8 > LDSROW ? Cout + 8 : LDSROW) + 64 * LDSROW) * 2, (hipStream_t)stream_>>>(a, (const __half *)weights, bias);
     RVA_HIP(ctx, hipGetLastError());
     return RVA_OK;
 }

@@ -149,8 +149,13 @@ class FusedYoloV8:
         h1, w1, h2, w2 = H // 2, W // 2, H // 4, W // 4
         h3, w3, h4, w4, h5, w5 = H // 8, W // 8, H // 16, W // 16, H // 32, W // 32
         # stem (planar input from K1)
-        sw = net.b0.conv.weight.detach().float().reshape(c1, 27).contiguous().to(self.dev)
-        sb = net.b0.conv.bias.detach().float().contiguous().to(self.dev)
+        sw = torch.zeros((64, 32), dtype=torch.float16)
+        w0 = net.b0.conv.weight.detach().float().cpu().reshape(c1, 9, 3)        # [co][j = c*3+ky][kx]
+        sw[:c1, 0:18] = w0[:, :, 0:2].reshape(c1, 18).half()                     # k = 2*j + kx, kx in {0,1}
+        sw[:c1, 18:27] = w0[:, :, 2].half()                                      # k = 18 + j, kx = 2
+        sb = torch.zeros((64,), dtype=torch.float32)
+        sb[:c1] = net.b0.conv.bias.detach().float().cpu()
+        sw, sb = sw.to(self.dev), sb.to(self.dev)
         self._keep += [sw, sb]
         x0 = _View(self._buf(B * h1 * w1, c1), 0, c1)
         L, ctx = self.L, self.ctx

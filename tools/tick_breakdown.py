@@ -43,7 +43,7 @@ def main(src, scale="s"):
     a, b = idx[-3], idx[-2]
     tick = rows[a:b]
     layers = plan_layers(scale)
-    det = [r for r in tick if any(k in r["Kernel_Name"] for k in ("k_conv_mfma", "k_stem", "k_maxpool5", "k_upsample2", "k_head"))]
+    det = [r for r in tick if any(k in r["Kernel_Name"] for k in ("k_conv_mfma", "k_conv_res", "k_stem", "k_maxpool5", "k_upsample2", "k_head"))]
     print(f"tick launches: {len(tick)}, detector launches: {len(det)} (plan {len(layers)})")
     tot = 0
     for r, (name, desc, fl, by) in zip(det, layers):
