@@ -229,6 +229,17 @@ int rva_yolo_head_f16(rva_ctx *ctx, const void *box_logits, int ldb, const void 
                       float stride, rva_stream_t stream);
 
 /* ----------------------------------------------------------------------------------------------
+ * K5 motion gate -- replaces MotionFilter.should_process (utils/frame_filter.py:26-40)
+ * for a tick of NV12 surfaces: gray -> 5x5 Gaussian -> |diff| against prev_blur[i] -> counts[i] = number of
+ * pixels with diff > 25 (device int32[n]; -1 where prev_blur[i] is NULL = first frame of that stream).
+ * blur_out[i] (device uint8 [h][w]) receives the new blurred frame; pass it as prev_blur next tick.
+ * The caller compares counts[i] / (w*h) >= motion_threshold (frame_filter.py:38-40).
+ * -------------------------------------------------------------------------------------------- */
+int rva_motion_nv12_batch(rva_ctx *ctx, const void *const *y_ptrs, const void *const *uv_ptrs,
+                          const int32_t *pitches, const void *const *prev_blur, void *const *blur_out, int n,
+                          int w, int h, int32_t *counts, rva_stream_t stream);
+
+/* ----------------------------------------------------------------------------------------------
  * Decode probe -- stands where VideoStream.open() (video_stream.py:61-95) sits.  librocdecode is
  * looked up with dlopen at run time; RVA_ERR_UNAVAILABLE if the machine does not have it.
  * -------------------------------------------------------------------------------------------- */

@@ -179,3 +179,15 @@ def clip_schedule(L, stride, overlap, n_frames):
     n = lib().orc_clip_schedule(L, stride, C.c_double(overlap), n_frames, cap, C.c_void_p(fired.ctypes.data),
                                 C.c_void_p(ids.ctypes.data))
     return fired[:n].tolist(), ids[:n].tolist()
+
+
+def motion_step_nv12(y, uv, w, h, prev_blur=None):
+    """One MotionFilter.should_process step on an NV12 frame: returns (changed-pixel count or -1, new blur)."""
+    y = np.ascontiguousarray(y); uv = np.ascontiguousarray(uv)
+    out = np.empty((h, w), np.uint8)
+    L = lib()
+    L.orc_motion_step_nv12.restype = C.c_long
+    pp = C.c_void_p(prev_blur.ctypes.data) if prev_blur is not None else None
+    n = L.orc_motion_step_nv12(C.c_void_p(y.ctypes.data), C.c_void_p(uv.ctypes.data), C.c_int(y.shape[1]), w, h, pp,
+                               C.c_void_p(out.ctypes.data))
+    return int(n), out

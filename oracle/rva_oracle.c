@@ -502,3 +502,63 @@ ORC_API int orc_clip_schedule(int L, int stride, double overlap, int n_frames, i
     free(buf);
     return clips;
 }
+
+/* ------------------------------------------------------------------ frame gates (UNPINNED: OpenCV absent) */
+/* utils/frame_filter.py:26-40 MotionFilter.should_process, one step:
+ *   gray = cvtColor(BGR2GRAY): (B*1868 + G*9617 + R*4899 + 8192) >> 14   (OpenCV 8-bit, yuv_shift = 14)
+ *   blur = GaussianBlur(gray, (5,5), 0): separable [1,4,6,4,1]/16, BORDER_REFLECT_101, OpenCV's 8-bit
+ *          fixed-point path is exact for these dyadic weights: (sum + 128) >> 8
+ *   diff = absdiff(blur, prev); count of diff > 25 (THRESH_BINARY)
+ * Writes the new blurred frame to `blur_out`; returns the changed-pixel count (-1 when prev == NULL). */
+static inline int refl101(int i, int n) { if (i < 0) i = -i; if (i >= n) i = 2 * n - 2 - i; return i; }
+
+ORC_API void orc_bgr_to_gray(const uint8_t *bgr, int w, int h, uint8_t *gray)
+{
+    for (size_t i = 0; i < (size_t)w * h; ++i)
+        gray[i] = (uint8_t)((bgr[3 * i] * 1868 + bgr[3 * i + 1] * 9617 + bgr[3 * i + 2] * 4899 + 8192) >> 14);
+}
+
+ORC_API void orc_gaussian5_u8(const uint8_t *src, int w, int h, uint8_t *dst)
+{
+    static const int k[5] = {1, 4, 6, 4, 1};
+    int *tmp = (int *)malloc(sizeof(int) * (size_t)w * h);
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            int s = 0;
+            for (int t = -2; t <= 2; ++t) s += k[t + 2] * src[(size_t)y * w + refl101(x + t, w)];
+            tmp[(size_t)y * w + x] = s;
+        }
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            int s = 0;
+            for (int t = -2; t <= 2; ++t) s += k[t + 2] * tmp[(size_t)refl101(y + t, h) * w + x];
+            dst[(size_t)y * w + x] = (uint8_t)((s + 128) >> 8);
+        }
+    free(tmp);
+}
+
+ORC_API long orc_motion_step_bgr(const uint8_t *bgr, int w, int h, const uint8_t *prev_blur, uint8_t *blur_out)
+{
+    uint8_t *gray = (uint8_t *)malloc((size_t)w * h);
+    orc_bgr_to_gray(bgr, w, h, gray);
+    orc_gaussian5_u8(gray, w, h, blur_out);
+    free(gray);
+    if (!prev_blur) return -1;
+    long cnt = 0;
+    for (size_t i = 0; i < (size_t)w * h; ++i) {
+        int d = (int)blur_out[i] - (int)prev_blur[i];
+        if (d < 0) d = -d;
+        cnt += d > 25;
+    }
+    return cnt;
+}
+
+ORC_API long orc_motion_step_nv12(const uint8_t *y, const uint8_t *uv, int pitch, int w, int h, const uint8_t *prev_blur,
+                                  uint8_t *blur_out)
+{
+    uint8_t *bgr = (uint8_t *)malloc((size_t)w * h * 3);
+    orc_nv12_to_bgr(y, uv, pitch, w, h, bgr);
+    long c = orc_motion_step_bgr(bgr, w, h, prev_blur, blur_out);
+    free(bgr);
+    return c;
+}

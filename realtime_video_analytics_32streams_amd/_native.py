@@ -18,7 +18,7 @@ PKG = Path(__file__).resolve().parent
 ROOT = PKG.parent
 CSRC = PKG / "csrc"
 LIB_PATH = PKG / "librva.so"
-SOURCES = ["rva_ctx.hip", "rva_preprocess.hip", "rva_postprocess.hip", "rva_tracker.hip", "rva_conv.hip"]
+SOURCES = ["rva_ctx.hip", "rva_preprocess.hip", "rva_postprocess.hip", "rva_tracker.hip", "rva_conv.hip", "rva_gates.hip"]
 # -ffp-contract=off: parity kernels must not fuse a*b+c (SURVEY.md hard part 4)
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off",
                "-Wall", "-Wno-unused-function"]
@@ -113,6 +113,7 @@ def lib() -> C.CDLL:
         "rva_tracker_state": (C.c_int, [_P, i64p, C.POINTER(C.c_int), _P]),
         "rva_tracker_set_next_id": (C.c_int, [_P, C.c_int64, _P]),
         "rva_decode_available": (C.c_int, [C.c_char_p, C.c_int]),
+        "rva_motion_nv12_batch": (C.c_int, [_P, pp, pp, i32p, pp, pp, C.c_int, C.c_int, C.c_int, _P, _P]),
         "rva_conv_cout_pad": (C.c_int, [C.c_int]),
         "rva_conv2d_nhwc_f16": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, C.c_int, _P, C.c_int] + [C.c_int] * 8 + [_P]),
         "rva_conv2d_nhwc_f16_v": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, C.c_int, _P, C.c_int] + [C.c_int] * 9 + [_P]),
@@ -139,7 +140,7 @@ EXPORTS = [
     "rva_tracker_destroy", "rva_tracker_update_f32", "rva_tracker_update_f64", "rva_tracker_new_counts",
     "rva_tracker_assign_ids", "rva_tracker_read", "rva_tracker_read_all", "rva_tracker_snapshot_async",
     "rva_tracker_snapshot_fetch", "rva_tracker_state",
-    "rva_tracker_set_next_id", "rva_decode_available", "rva_conv_cout_pad", "rva_conv2d_nhwc_f16", "rva_conv2d_nhwc_f16_v", "rva_stem_conv_f16",
+    "rva_tracker_set_next_id", "rva_decode_available", "rva_motion_nv12_batch", "rva_conv_cout_pad", "rva_conv2d_nhwc_f16", "rva_conv2d_nhwc_f16_v", "rva_stem_conv_f16",
     "rva_maxpool5_nhwc_f16", "rva_upsample2x_nhwc_f16", "rva_yolo_head_f16",
 ]
 

@@ -28,6 +28,7 @@ import torch
 from . import ops
 from .config import PipelineConfig, StreamConfig
 from .detector import HipYoloDetector, create_detector
+from .gates import AdaptiveFps, MotionGate
 from .tracker import IouTracker, Track
 from .video_stream import FramePacket, open_stream
 
@@ -72,6 +73,34 @@ class TickPipeline:
         self.global_index = [first_global_index + i for i in range(len(self.streams))]
         self.n_global = n_global_streams or len(self.streams)
         self._tick = 0
+        # pre-detector gates, configured by the reference's StreamConfig keys
+        self.adaptive = [AdaptiveFps(s) for s in self.streams]
+        self._motion: Optional[MotionGate] = None
+        self._motion_on = [bool(s.motion_filter) for s in self.streams]
+
+    def _gate(self, packets: Sequence[Optional[FramePacket]]) -> List[bool]:
+        """should-process decision per stream, in the reference's order: motion gate (pipeline.py:156-163), then
+        adaptive-fps gate (:165-170).  ``AdaptiveFps.should_process`` runs for every packet (the frame index of
+        pipeline.py:144 advances even when the motion gate already dropped the frame)."""
+        n = len(packets)
+        motion_ok = [True] * n
+        if any(self._motion_on):
+            surf = [p.frame if (p is not None and self._motion_on[i] and isinstance(p.frame, ops.Nv12Surface)) else None
+                    for i, p in enumerate(packets)]
+            first = next((f for f in surf if f is not None), None)
+            if first is not None:
+                if self._motion is None:
+                    self._motion = MotionGate(n, first.width, first.height, [s.motion_threshold for s in self.streams],
+                                              ctx=self.detector.ctx)
+                motion_ok = self._motion.step(surf)
+        out = []
+        for i, p in enumerate(packets):
+            if p is None:
+                out.append(True)
+                continue
+            adaptive_ok = self.adaptive[i].should_process()
+            out.append(motion_ok[i] and adaptive_ok)
+        return out
 
     @classmethod
     def from_config(cls, cfg: PipelineConfig, **kw) -> "TickPipeline":
@@ -105,6 +134,8 @@ class TickPipeline:
     def tick(self, process: Optional[Sequence[bool]] = None) -> TickResult:
         t0 = time.perf_counter()
         packets = [src.next_packet() for src in self.sources]
+        if process is None and (any(self._motion_on) or any(a.enabled for a in self.adaptive)):
+            process = self._gate(packets)
         post = self.enqueue(packets, process)
         tables = self.tracker.device_tracker.read_all()          # the one host sync of the tick
         names = [n for n, p in zip(self.names, packets) if p is not None]
@@ -124,5 +155,8 @@ class TickPipeline:
                 row += 1
         for n in names:
             self.counters.update(n, 1, emitted.get(n, 0), len(tracks[n]))
+        for i, p in enumerate(packets):                     # pipeline.py:197 / :222 _adjust_adaptive_state
+            if p is not None:
+                self.adaptive[i].update(emitted.get(self.names[i], 0), len(tracks[self.names[i]]))
         self._tick += 1
         return TickResult(self._tick - 1, tracks, emitted, time.perf_counter() - t0)
