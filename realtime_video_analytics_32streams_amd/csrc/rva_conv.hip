@@ -232,6 +232,184 @@ hipError_t launch_conv(const ConvArgs &a, hipStream_t s)
 
 
 // ---------------------------------------------------------------------------------------------------
+// 3x3 stride-1 convolution, row-reuse variant.  A tile is 4*WPX CONSECUTIVE raster pixels of one image, so for
+// a fixed vertical tap dy the inputs of all three horizontal taps form ONE contiguous run of BM+2 pixels
+// (raster index p0 + (dy-1)*W - 1 ...).  Per K-step (dy, 32-channel chunk) that run is staged once and the
+// three dx taps read their B fragments from it at row offset dx; lanes whose ox+dx-1 falls off the image
+// row (raster wrap) zero their fragment.  3x fewer activation loads and barriers per MFMA than gathering per
+// tap, while keeping the small tiles (high occupancy) the autotuner prefers.
+struct RowArgs {
+    const __half *in; int ldi;
+    const __half *w; const float *bias;
+    __half *out; int ldo;
+    const __half *res; int ldr;
+    int H, W, Cin, CinPad, Cout, act, n_tiles, tiles_per_img;
+};
+
+template <int BN, int WPX>
+__global__ void __launch_bounds__(256) k_conv3_row(RowArgs a)
+{
+    constexpr int BM = 4 * WPX;
+    constexpr int AROWS = BM + 2;
+    constexpr int NA = (AROWS * 4 + 255) / 256;          // activation chunks per thread per step
+    constexpr int NW = BN * 12 / 256;                      // weight chunks per thread per step (3 taps x 4 parts)
+    constexpr int WROW = 3 * LDSROW;                       // halfs per weight row: [3 dx][32 + pad]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __half *actT = (__half *)smem;                         // [2][AROWS][LDSROW]
+    __half *wT = actT + 2 * AROWS * LDSROW;                // [2][BN][3][LDSROW]
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n_tile = blockIdx.x % a.n_tiles;
+    const int t = blockIdx.x / a.n_tiles;
+    const int b = t / a.tiles_per_img, p0 = (t - b * a.tiles_per_img) * BM;
+    const int HW = a.H * a.W, n0 = n_tile * BN;
+    const int cpt = a.CinPad >> 5;
+    const int nsteps = 3 * cpt;
+    const size_t wrow = (size_t)9 * a.CinPad;
+    const __half *img = a.in + (size_t)b * HW * a.ldi;
+
+    u4 ra[NA], rw[NW];
+    auto gload = [&](int dy, int cc) {
+        const int q0 = p0 + (dy - 1) * a.W - 1;            // raster index of tile row 0
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int c = tid + 256 * i, r = c >> 2, part = c & 3;
+            const int q = q0 + r;
+            ra[i] = u4{0u, 0u, 0u, 0u};
+            if (r < AROWS && (unsigned)q < (unsigned)HW && (cc << 5) + part * 8 < a.Cin)
+                ra[i] = *reinterpret_cast<const u4 *>(img + (size_t)q * a.ldi + (cc << 5) + part * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int c = tid + 256 * i, part = c & 3, rowi = c >> 2, dx = rowi % 3, co = rowi / 3;
+            rw[i] = *reinterpret_cast<const u4 *>(a.w + (size_t)(n0 + co) * wrow + (size_t)(dy * 3 + dx) * a.CinPad + (cc << 5) + part * 8);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int c = tid + 256 * i, r = c >> 2, part = c & 3;
+            if (r < AROWS) *reinterpret_cast<u4 *>(actT + ((size_t)buf * AROWS + r) * LDSROW + part * 8) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int c = tid + 256 * i, part = c & 3, rowi = c >> 2;       // rowi = co*3 + dx
+            *reinterpret_cast<u4 *>(wT + ((size_t)buf * BN * 3 + rowi) * LDSROW + part * 8) = rw[i];
+        }
+    };
+
+    // horizontal validity of this lane's pixels for dx = 0 (needs ox >= 1) and dx = 2 (needs ox <= W-2)
+    bool okl[WPX / 16], okr[WPX / 16];
+#pragma unroll
+    for (int j = 0; j < WPX / 16; ++j) {
+        const int p = min(p0 + wv * WPX + 16 * j + (lane & 15), HW - 1);
+        const int ox = p % a.W;
+        okl[j] = ox >= 1;
+        okr[j] = ox <= a.W - 2;
+    }
+
+    f4 acc[BN / 16][WPX / 16];
+#pragma unroll
+    for (int i = 0; i < BN / 16; ++i)
+#pragma unroll
+        for (int j = 0; j < WPX / 16; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+    int dy = 0, cc = 0;
+    gload(0, 0);
+    lstore(0);
+    __syncthreads();
+    const h8 hz = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int s = 0; s < nsteps; ++s) {
+        const int buf = s & 1;
+        int ndy = dy, ncc = cc + 1;
+        if (ncc == cpt) { ncc = 0; ++ndy; }
+        const bool more = s + 1 < nsteps;
+        if (more) gload(ndy, ncc);
+        const __half *ab = actT + ((size_t)buf * AROWS + wv * WPX + (lane & 15)) * LDSROW + (lane >> 4) * 8;
+        const __half *wb = wT + ((size_t)buf * BN * 3 + (lane & 15) * 3) * LDSROW + (lane >> 4) * 8;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            h8 bf[WPX / 16];
+#pragma unroll
+            for (int j = 0; j < WPX / 16; ++j) {
+                bf[j] = *reinterpret_cast<const h8 *>(ab + (size_t)(j * 16 + dx) * LDSROW);
+                if (dx == 0 && !okl[j]) bf[j] = hz;
+                if (dx == 2 && !okr[j]) bf[j] = hz;
+            }
+#pragma unroll
+            for (int i = 0; i < BN / 16; ++i) {
+                const h8 af = *reinterpret_cast<const h8 *>(wb + (size_t)(i * 48 + dx) * LDSROW);
+#pragma unroll
+                for (int j = 0; j < WPX / 16; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (more) lstore(buf ^ 1);
+        __syncthreads();
+        dy = ndy; cc = ncc;
+    }
+
+    constexpr int SROW = BN + 8;
+    __half *stage = (__half *)smem;
+#pragma unroll
+    for (int i = 0; i < BN / 16; ++i) {
+        const int co = 16 * i + (lane >> 4) * 4;
+        const float4 bv = *reinterpret_cast<const float4 *>(a.bias + n0 + co);
+#pragma unroll
+        for (int j = 0; j < WPX / 16; ++j) {
+            float v0 = acc[i][j][0] + bv.x, v1 = acc[i][j][1] + bv.y, v2 = acc[i][j][2] + bv.z, v3 = acc[i][j][3] + bv.w;
+            if (a.act) { v0 = silu_f(v0); v1 = silu_f(v1); v2 = silu_f(v2); v3 = silu_f(v3); }
+            const int px = wv * WPX + 16 * j + (lane & 15);
+            __half2 lo = __floats2half2_rn(v0, v1), hi = __floats2half2_rn(v2, v3);
+            uint2 pk;
+            pk.x = *reinterpret_cast<uint32_t *>(&lo);
+            pk.y = *reinterpret_cast<uint32_t *>(&hi);
+            *reinterpret_cast<uint2 *>(stage + (size_t)px * SROW + co) = pk;
+        }
+    }
+    __syncthreads();
+    constexpr int CPR = BN / 8;
+    const size_t mbase = (size_t)b * HW + p0;
+#pragma unroll 4
+    for (int q = tid; q < BM * CPR; q += 256) {
+        const int row = q / CPR, pc = q - row * CPR;
+        const int co = n0 + pc * 8;
+        if (p0 + row < HW && co < a.Cout) {
+            uint4 v = *reinterpret_cast<const uint4 *>(stage + (size_t)row * SROW + pc * 8);
+            const size_t m = mbase + row;
+            if (a.res) {
+                const uint4 r = *reinterpret_cast<const uint4 *>(a.res + m * a.ldr + co);
+                __half2 *vh = reinterpret_cast<__half2 *>(&v);
+                const __half2 *rh = reinterpret_cast<const __half2 *>(&r);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float2 x = __half22float2(vh[u]), y = __half22float2(rh[u]);
+                    vh[u] = __floats2half2_rn(x.x + y.x, x.y + y.y);
+                }
+            }
+            *reinterpret_cast<uint4 *>(a.out + m * a.ldo + co) = v;
+        }
+    }
+}
+
+template <int BN, int WPX>
+hipError_t launch_row(RowArgs &a, int batch, hipStream_t s)
+{
+    constexpr int BM = 4 * WPX;
+    constexpr size_t op = (size_t)2 * ((BM + 2) + BN * 3) * LDSROW * 2;
+    constexpr size_t st = (size_t)BM * (BN + 8) * 2;
+    constexpr size_t smem = op > st ? op : st;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_conv3_row<BN, WPX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    a.tiles_per_img = rva_ceil_div(a.H * a.W, BM);
+    k_conv3_row<BN, WPX><<<batch * a.tiles_per_img * a.n_tiles, 256, smem, s>>>(a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Resident-chunk convolution (3x3 stride 1, and 1x1): persistent blocks, one per CU.
 //
 // A work item is (tile, channel chunk).  A tile = 4*WPX consecutive output pixels (raster order; of one
@@ -726,6 +904,7 @@ extern "C" {
 // variant: 0 = heuristic choice; otherwise an explicit kernel (used by the plan's per-layer autotune):
 //   1..4  gather kernel  <BN,WPX> = <64,64> <64,32> <128,64> <128,32>
 //   5..8  resident kernel <BN,WPX> = <64,64> <64,32> <128,64> <128,32>   (stride 1 only)
+//   9..12 row-reuse kernel, same tile order                               (3x3 stride 1 only)
 int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *weights, const float *bias, void *out,
                           int ldo, const void *residual, int ldr, int batch, int H, int W, int Cin, int Cout, int ksize,
                           int stride, int act, int variant, rva_stream_t stream_);
@@ -745,7 +924,7 @@ int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *wei
     if (!ctx) return RVA_ERR_ARG;
     hipStream_t s = (hipStream_t)stream_;
     if (!in || !weights || !bias || !out || batch <= 0 || H <= 0 || W <= 0 || (ksize != 1 && ksize != 3) ||
-        (stride != 1 && stride != 2) || Cin % 8 || Cout % 8 || ldi % 8 || ldo % 8 || (residual && ldr % 8) || variant < 0 || variant > 8 ||
+        (stride != 1 && stride != 2) || Cin % 8 || Cout % 8 || ldi % 8 || ldo % 8 || (residual && ldr % 8) || variant < 0 || variant > 12 ||
         ((uintptr_t)in | (uintptr_t)out | (uintptr_t)weights | (uintptr_t)residual) % 16)
         return rva_fail(ctx, RVA_ERR_ARG, "rva_conv2d_nhwc_f16: unsupported shape/alignment (Cin%%8, Cout%%8, ld%%8, 16-byte pointers)");
     ConvArgs a{};
@@ -776,6 +955,15 @@ int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *wei
 #define RVA_V(BN_, WPX_) (ksize == 1 ? launch_conv<BN_, WPX_, 1>(a, s) : launch_conv<BN_, WPX_, 3>(a, s))
             ev = v == 0 ? RVA_V(64, 64) : v == 1 ? RVA_V(64, 32) : v == 2 ? RVA_V(128, 64) : RVA_V(128, 32);
 #undef RVA_V
+        } else if (variant >= 9) {
+            if (ksize == 3 && stride == 1) {
+                RowArgs rr{};
+                rr.in = a.in; rr.ldi = ldi; rr.w = a.w; rr.bias = bias; rr.out = a.out; rr.ldo = ldo; rr.res = a.res; rr.ldr = ldr;
+                rr.H = H; rr.W = W; rr.Cin = Cin; rr.CinPad = a.CinPad; rr.Cout = Cout; rr.act = act;
+                rr.n_tiles = cpad / vbn;
+                ev = v == 0 ? launch_row<64, 64>(rr, batch, s) : v == 1 ? launch_row<64, 32>(rr, batch, s)
+                   : v == 2 ? launch_row<128, 64>(rr, batch, s) : launch_row<128, 32>(rr, batch, s);
+            }
         } else if (stride == 1) {
             ResArgs ra{};
             ra.in = a.in; ra.ldi = ldi; ra.w = a.w; ra.bias = bias; ra.out = a.out; ra.ldo = ldo; ra.res = a.res; ra.ldr = ldr;

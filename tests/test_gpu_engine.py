@@ -69,6 +69,39 @@ def test_conv_primitive_matches_fp32_reference(shape):
         assert torch.all(out_full[..., :oe] == 7.0)        # the neighbouring slice is untouched
 
 
+@pytest.mark.parametrize("shape", [(2, 20, 20, 64, 64, 3, 1), (3, 17, 23, 96, 128, 3, 1), (1, 40, 40, 128, 128, 3, 1), (2, 9, 7, 32, 64, 3, 1),
+                                   (2, 20, 20, 128, 128, 1, 1), (2, 20, 20, 64, 128, 3, 2)])
+def test_every_conv_variant_agrees(shape):
+    """All kernel variants the autotuner may pick (gather / resident / row-reuse, every tile) give the same layer."""
+    B, H, W, Cin, Cout, k, stride = shape
+    g = torch.Generator().manual_seed(7)
+    x = (torch.randn((B, H, W, Cin), generator=g) * 0.5).half().cuda()
+    w = (torch.randn((Cout, Cin, k, k), generator=g) / (Cin * k * k) ** 0.5).half()
+    b = torch.randn((Cout,), generator=g) * 0.1
+    res = (torch.randn((B, (H - 1) // stride + 1 if k == 3 else H, (W - 1) // stride + 1 if k == 3 else W, Cout), generator=g) * 0.5).half().cuda()
+    L, ctx = N.lib(), ops.context()
+    cpad, cinp = L.rva_conv_cout_pad(Cout), (Cin + 31) // 32 * 32
+    wp = torch.zeros((cpad, k * k, cinp), dtype=torch.float16); wp[:Cout, :, :Cin] = w.permute(0, 2, 3, 1).reshape(Cout, k * k, Cin)
+    bp = torch.zeros(cpad); bp[:Cout] = b
+    wp, bp = wp.cuda(), bp.cuda()
+    want = _conv_ref(x, w.cuda(), b.cuda(), k, stride, 1, res)
+    ran = []
+    for variant in range(0, 13):
+        out = torch.zeros_like(res)
+        rc = L.rva_conv2d_nhwc_f16_v(ctx.handle, C.c_void_p(x.data_ptr()), Cin, C.c_void_p(wp.data_ptr()), C.c_void_p(bp.data_ptr()),
+                                     C.c_void_p(out.data_ptr()), Cout, C.c_void_p(res.data_ptr()), Cout, B, H, W, Cin, Cout, k, stride, 1,
+                                     variant, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        if rc != N.RVA_OK:
+            continue
+        torch.cuda.synchronize()
+        err = (out.float() - want).abs().max().item()
+        assert err < 2e-2 + 2e-3 * want.abs().max().item(), (variant, err)
+        ran.append(variant)
+    assert 0 in ran and len(ran) >= 3, ran
+    if k == 3 and stride == 1:
+        assert any(v >= 9 for v in ran), ran       # the row-reuse kernel took part
+
+
 def test_pool_upsample_head_primitives():
     L, ctx = N.lib(), ops.context()
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
