@@ -55,17 +55,19 @@ constexpr int LDSROW = 40;  // halfs per staged row: 32 data + 8 pad (80 B) -> c
 // division sequence here, which dominated the epilogues (64-128 SiLUs per thread per tile)
 __device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
-template <int BN, int WPX, int KS>
+template <int BN, int WPX, int KS, int BK>
 __global__ void __launch_bounds__(256) k_conv_mfma(ConvArgs a)
 {
     constexpr int BM = 4 * WPX;
-    constexpr int NA = WPX / 16;   // activation 16-byte chunks per thread per step
-    constexpr int NW = BN / 64;    // weight chunks per thread per step
+    constexpr int PARTS = BK / 8;                 // 16-byte chunks per staged row
+    constexpr int ROWH = BK + 8;                  // halfs per LDS row (16-byte pad)
+    constexpr int NA = BM * PARTS / 256;          // activation chunks per thread per step
+    constexpr int NW = BN * PARTS / 256;          // weight chunks per thread per step
     constexpr int TAPS = KS * KS;
     constexpr int PAD = KS / 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __half *actT = (__half *)smem;                         // [2][BM][LDSROW]
-    __half *wT = actT + 2 * BM * LDSROW;                   // [2][BN][LDSROW]
+    __half *actT = (__half *)smem;                         // [2][BM][ROWH]
+    __half *wT = actT + 2 * BM * ROWH;                     // [2][BN][ROWH]
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     // XCD-aware tile order: blocks id and id+8 share an XCD (round-robin dispatch), so the n-tiles of
@@ -87,10 +89,11 @@ __global__ void __launch_bounds__(256) k_conv_mfma(ConvArgs a)
 
     // per-thread source rows (fixed across K-steps)
     int pix0[NA], iy0[NA], ix0[NA];
-    const int part = tid & 3;
+    const int part = tid % PARTS;
+    constexpr int RPT = 256 / PARTS;              // rows covered per pass of the 256 threads
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        const int m = m0 + (tid >> 2) + 64 * i;
+        const int m = m0 + tid / PARTS + RPT * i;
         if (m < a.M) {
             const int b = m / HoWo, rem = m - b * HoWo;
             const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
@@ -101,7 +104,7 @@ __global__ void __launch_bounds__(256) k_conv_mfma(ConvArgs a)
             iy0[i] = -100000; ix0[i] = -100000; pix0[i] = 0;
         }
     }
-    const int cpt = a.CinPad >> 5;       // 32-channel chunks per tap
+    const int cpt = a.CinPad / BK;       // BK-channel chunks per tap
     const int nsteps = TAPS * cpt;
     const size_t wrow = (size_t)TAPS * a.CinPad;
 
@@ -111,27 +114,27 @@ __global__ void __launch_bounds__(256) k_conv_mfma(ConvArgs a)
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int iy = iy0[i] + dy, ix = ix0[i] + dx;
-            const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W && (cc << 5) + part * 8 < a.Cin;
+            const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W && cc * BK + part * 8 < a.Cin;
             ra[i] = u4{0u, 0u, 0u, 0u};
             if (ok) {
-                const __half *p = a.in + (size_t)(pix0[i] + dy * a.W + dx) * a.ldi + (cc << 5) + part * 8;
+                const __half *p = a.in + (size_t)(pix0[i] + dy * a.W + dx) * a.ldi + cc * BK + part * 8;
                 ra[i] = *reinterpret_cast<const u4 *>(p);
             }
         }
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
-            const int co = n0 + (tid >> 2) + 64 * i;
-            const __half *p = a.w + (size_t)co * wrow + (size_t)tap * a.CinPad + (cc << 5) + part * 8;
+            const int co = n0 + tid / PARTS + RPT * i;
+            const __half *p = a.w + (size_t)co * wrow + (size_t)tap * a.CinPad + cc * BK + part * 8;
             rw[i] = *reinterpret_cast<const u4 *>(p);
         }
     };
     auto lstore = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < NA; ++i)
-            *reinterpret_cast<u4 *>(actT + ((size_t)buf * BM + (tid >> 2) + 64 * i) * LDSROW + part * 8) = ra[i];
+            *reinterpret_cast<u4 *>(actT + ((size_t)buf * BM + tid / PARTS + RPT * i) * ROWH + part * 8) = ra[i];
 #pragma unroll
         for (int i = 0; i < NW; ++i)
-            *reinterpret_cast<u4 *>(wT + ((size_t)buf * BN + (tid >> 2) + 64 * i) * LDSROW + part * 8) = rw[i];
+            *reinterpret_cast<u4 *>(wT + ((size_t)buf * BN + tid / PARTS + RPT * i) * ROWH + part * 8) = rw[i];
     };
 
     f4 acc[BN / 16][WPX / 16];
@@ -150,16 +153,19 @@ __global__ void __launch_bounds__(256) k_conv_mfma(ConvArgs a)
         if (ncc == cpt) { ncc = 0; ++ntap; }
         const bool more = s + 1 < nsteps;
         if (more) gload(ntap, ncc);                      // in flight under the MFMAs below
-        const __half *ab = actT + ((size_t)buf * BM + wv * WPX + (lane & 15)) * LDSROW + (lane >> 4) * 8;
-        const __half *wb = wT + ((size_t)buf * BN + (lane & 15)) * LDSROW + (lane >> 4) * 8;
-        h8 bf[WPX / 16];
+        const __half *ab = actT + ((size_t)buf * BM + wv * WPX + (lane & 15)) * ROWH + (lane >> 4) * 8;
+        const __half *wb = wT + ((size_t)buf * BN + (lane & 15)) * ROWH + (lane >> 4) * 8;
 #pragma unroll
-        for (int j = 0; j < WPX / 16; ++j) bf[j] = *reinterpret_cast<const h8 *>(ab + j * 16 * LDSROW);
+        for (int ks = 0; ks < BK / 32; ++ks) {
+            h8 bf[WPX / 16];
 #pragma unroll
-        for (int i = 0; i < BN / 16; ++i) {
-            const h8 af = *reinterpret_cast<const h8 *>(wb + i * 16 * LDSROW);
+            for (int j = 0; j < WPX / 16; ++j) bf[j] = *reinterpret_cast<const h8 *>(ab + j * 16 * ROWH + ks * 32);
 #pragma unroll
-            for (int j = 0; j < WPX / 16; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[j], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < BN / 16; ++i) {
+                const h8 af = *reinterpret_cast<const h8 *>(wb + i * 16 * ROWH + ks * 32);
+#pragma unroll
+                for (int j = 0; j < WPX / 16; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[j], acc[i][j], 0, 0, 0);
+            }
         }
         if (more) lstore(buf ^ 1);
         __syncthreads();
@@ -208,25 +214,26 @@ __global__ void __launch_bounds__(256) k_conv_mfma(ConvArgs a)
     }
 }
 
-template <int BN, int WPX, int KS>
+template <int BN, int WPX, int KS, int BK>
 constexpr size_t conv_smem()
 {
-    constexpr size_t op = (size_t)2 * (4 * WPX + BN) * LDSROW * 2;
+    constexpr size_t op = (size_t)2 * (4 * WPX + BN) * (BK + 8) * 2;
     constexpr size_t st = (size_t)4 * WPX * (BN + 8) * 2;
     return op > st ? op : st;
 }
 
-template <int BN, int WPX, int KS>
+template <int BN, int WPX, int KS, int BK = 32>
 hipError_t launch_conv(const ConvArgs &a, hipStream_t s)
 {
-    constexpr size_t smem = conv_smem<BN, WPX, KS>();
+    if (a.CinPad % BK) return hipErrorInvalidValue;
+    constexpr size_t smem = conv_smem<BN, WPX, KS, BK>();
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_conv_mfma<BN, WPX, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipError_t e = hipFuncSetAttribute((const void *)k_conv_mfma<BN, WPX, KS, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
         attr = true;
     }
-    k_conv_mfma<BN, WPX, KS><<<a.m_tiles * a.n_tiles, 256, smem, s>>>(a);
+    k_conv_mfma<BN, WPX, KS, BK><<<a.m_tiles * a.n_tiles, 256, smem, s>>>(a);
     return hipGetLastError();
 }
 
@@ -905,6 +912,7 @@ extern "C" {
 //   1..4  gather kernel  <BN,WPX> = <64,64> <64,32> <128,64> <128,32>
 //   5..8  resident kernel <BN,WPX> = <64,64> <64,32> <128,64> <128,32>   (stride 1 only)
 //   9..12 row-reuse kernel, same tile order                               (3x3 stride 1 only)
+//   13..16 gather kernel with 64-channel K-steps, same tile order         (Cin padded to 64)
 int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *weights, const float *bias, void *out,
                           int ldo, const void *residual, int ldr, int batch, int H, int W, int Cin, int Cout, int ksize,
                           int stride, int act, int variant, rva_stream_t stream_);
@@ -924,7 +932,7 @@ int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *wei
     if (!ctx) return RVA_ERR_ARG;
     hipStream_t s = (hipStream_t)stream_;
     if (!in || !weights || !bias || !out || batch <= 0 || H <= 0 || W <= 0 || (ksize != 1 && ksize != 3) ||
-        (stride != 1 && stride != 2) || Cin % 8 || Cout % 8 || ldi % 8 || ldo % 8 || (residual && ldr % 8) || variant < 0 || variant > 12 ||
+        (stride != 1 && stride != 2) || Cin % 8 || Cout % 8 || ldi % 8 || ldo % 8 || (residual && ldr % 8) || variant < 0 || variant > 16 ||
         ((uintptr_t)in | (uintptr_t)out | (uintptr_t)weights | (uintptr_t)residual) % 16)
         return rva_fail(ctx, RVA_ERR_ARG, "rva_conv2d_nhwc_f16: unsupported shape/alignment (Cin%%8, Cout%%8, ld%%8, 16-byte pointers)");
     ConvArgs a{};
@@ -955,6 +963,12 @@ int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *wei
 #define RVA_V(BN_, WPX_) (ksize == 1 ? launch_conv<BN_, WPX_, 1>(a, s) : launch_conv<BN_, WPX_, 3>(a, s))
             ev = v == 0 ? RVA_V(64, 64) : v == 1 ? RVA_V(64, 32) : v == 2 ? RVA_V(128, 64) : RVA_V(128, 32);
 #undef RVA_V
+        } else if (variant >= 13) {
+            a.n_tiles = cpad / vbn;
+            a.m_tiles = rva_ceil_div(a.M, 4 * vwpx);
+#define RVA_V64(BN_, WPX_) (ksize == 1 ? launch_conv<BN_, WPX_, 1, 64>(a, s) : launch_conv<BN_, WPX_, 3, 64>(a, s))
+            ev = v == 0 ? RVA_V64(64, 64) : v == 1 ? RVA_V64(64, 32) : v == 2 ? RVA_V64(128, 64) : RVA_V64(128, 32);
+#undef RVA_V64
         } else if (variant >= 9) {
             if (ksize == 3 && stride == 1) {
                 RowArgs rr{};
