@@ -152,6 +152,11 @@ int rva_tracker_update_f64(rva_tracker *trk, const int32_t *active, const int32_
                            const double *boxes, const double *conf, const int64_t *cls,
                            rva_stream_t stream);
 
+/* Per-stream multiplier applied (in float64) to the widened box of every detection fed through
+ * rva_tracker_update_f32: _rescale_detections of pipeline.py:224-240 (1 / max(downsample_ratio, 1e-6); 1.0 = off).
+ * Host-synchronous; scales: host double[n_streams]. */
+int rva_tracker_set_box_scale(rva_tracker *trk, const double *scales);
+
 /* Device address of int32 new_counts[n_streams] written by the last update (for the multi-GPU
  * all-gather of SURVEY.md 8e). */
 int32_t *rva_tracker_new_counts(rva_tracker *trk);
@@ -238,6 +243,26 @@ int rva_yolo_head_f16(rva_ctx *ctx, const void *box_logits, int ldb, const void 
 int rva_motion_nv12_batch(rva_ctx *ctx, const void *const *y_ptrs, const void *const *uv_ptrs,
                           const int32_t *pitches, const void *const *prev_blur, void *const *blur_out, int n,
                           int w, int h, int32_t *counts, rva_stream_t stream);
+/* Same with per-stream ROI masks (uint8 [h][w], 0 = outside; entries may be NULL) applied first, and for uint8 BGR
+ * device images (the downsampled frames): the gate sees what the reference's frame_for_detection holds. */
+int rva_motion_nv12_masked_batch(rva_ctx *ctx, const void *const *y_ptrs, const void *const *uv_ptrs,
+                                 const int32_t *pitches, const void *const *masks, const void *const *prev_blur,
+                                 void *const *blur_out, int n, int w, int h, int32_t *counts, rva_stream_t stream);
+int rva_motion_bgr_batch(rva_ctx *ctx, const void *const *frames, const int32_t *row_bytes,
+                         const void *const *prev_blur, void *const *blur_out, int n, int w, int h, int32_t *counts,
+                         rva_stream_t stream);
+
+/* ROI + downsample in front of the detector (utils/frame_filter.py:43-57, pipeline.py:149-154):
+ * rva_preprocess_nv12_masked_batch = rva_preprocess_nv12_batch with apply_roi (pixels whose mask byte is 0
+ * become BGR 0,0,0 before the resize); rva_resize_nv12_to_bgr_batch = apply_roi + downsample: cv2.resize
+ * INTER_LINEAR to (dst_w, dst_h) as uint8 BGR images out_bgr[n][dst_h][dst_w][3] (feed rva_preprocess_bgr_batch). */
+int rva_preprocess_nv12_masked_batch(rva_ctx *ctx, const void *const *y_ptrs, const void *const *uv_ptrs,
+                                     const int32_t *pitches, const void *const *masks, int n, int src_w, int src_h,
+                                     void *out, int out_dtype, int dst_w, int dst_h, rva_letterbox *meta_out,
+                                     rva_stream_t stream);
+int rva_resize_nv12_to_bgr_batch(rva_ctx *ctx, const void *const *y_ptrs, const void *const *uv_ptrs,
+                                 const int32_t *pitches, const void *const *masks, int n, int src_w, int src_h,
+                                 void *out_bgr, int dst_w, int dst_h, rva_stream_t stream);
 
 /* ----------------------------------------------------------------------------------------------
  * Decode probe -- stands where VideoStream.open() (video_stream.py:61-95) sits.  librocdecode is

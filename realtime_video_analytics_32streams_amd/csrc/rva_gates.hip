@@ -12,6 +12,7 @@ struct K5Args {
     const uint8_t *y[RVA_MAX_BATCH];
     const uint8_t *uv[RVA_MAX_BATCH];
     const uint8_t *prev[RVA_MAX_BATCH];   // nullptr: first frame of the stream (count = -1)
+    const uint8_t *mask[RVA_MAX_BATCH];   // optional ROI mask uint8 [h][w] (apply_roi runs before the motion gate)
     uint8_t *out[RVA_MAX_BATCH];
     int32_t pitch[RVA_MAX_BATCH];
     int w, h;
@@ -23,6 +24,7 @@ constexpr int TW = 64, TH = 16, HW_ = TW + 4, HH_ = TH + 4;
 __device__ __forceinline__ int refl101(int i, int n) { if (i < 0) i = -i; if (i >= n) i = 2 * n - 2 - i; return i; }
 __device__ __forceinline__ int clip8(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
 
+template <bool NV12>
 __global__ void __launch_bounds__(256) k5_motion(K5Args a)
 {
     __shared__ uint8_t gray[HH_][HW_ + 4];
@@ -30,15 +32,22 @@ __global__ void __launch_bounds__(256) k5_motion(K5Args a)
     __shared__ int wsum[4];
     const int s = blockIdx.z, tid = threadIdx.x;
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
-    const uint8_t *yp = a.y[s], *uvp = a.uv[s];
+    const uint8_t *yp = a.y[s], *uvp = a.uv[s], *mk = a.mask[s];
     const int pitch = a.pitch[s];
     for (int i = tid; i < HH_ * HW_; i += 256) {
         const int r = i / HW_, c = i - r * HW_;
         const int py = refl101(y0 + r - 2, a.h), px = refl101(x0 + c - 2, a.w);
-        const int Y = yp[(size_t)py * pitch + px];
-        const uint8_t *u = uvp + (size_t)(py >> 1) * pitch + ((px >> 1) << 1);
-        const int cc = 298 * (Y - 16), d = u[0] - 128, e = u[1] - 128;
-        const int B = clip8((cc + 516 * d + 128) >> 8), G = clip8((cc - 100 * d - 208 * e + 128) >> 8), R = clip8((cc + 409 * e + 128) >> 8);
+        int B, G, R;
+        if (NV12) {
+            const int Y = yp[(size_t)py * pitch + px];
+            const uint8_t *u = uvp + (size_t)(py >> 1) * pitch + ((px >> 1) << 1);
+            const int cc = 298 * (Y - 16), d = u[0] - 128, e = u[1] - 128;
+            B = clip8((cc + 516 * d + 128) >> 8); G = clip8((cc - 100 * d - 208 * e + 128) >> 8); R = clip8((cc + 409 * e + 128) >> 8);
+        } else {
+            const uint8_t *q = yp + (size_t)py * pitch + (size_t)px * 3;
+            B = q[0]; G = q[1]; R = q[2];
+        }
+        if (mk && mk[(size_t)py * a.w + px] == 0) B = G = R = 0;
         gray[r][c] = (uint8_t)((B * 1868 + G * 9617 + R * 4899 + 8192) >> 14);
     }
     __syncthreads();
@@ -75,24 +84,50 @@ __global__ void k5_init(int32_t *counts, K5Args a, int n)
 
 }  // namespace
 
-extern "C" int rva_motion_nv12_batch(rva_ctx *ctx, const void *const *y_ptrs, const void *const *uv_ptrs,
-                                     const int32_t *pitches, const void *const *prev_blur, void *const *blur_out, int n,
-                                     int w, int h, int32_t *counts, rva_stream_t stream_)
+static int motion_common(rva_ctx *ctx, bool nv12, const void *const *y_ptrs, const void *const *uv_ptrs,
+                         const int32_t *pitches, const void *const *masks, const void *const *prev_blur, void *const *blur_out,
+                         int n, int w, int h, int32_t *counts, rva_stream_t stream_)
 {
-    if (!ctx || !y_ptrs || !uv_ptrs || !pitches || !prev_blur || !blur_out || !counts || n <= 0 || n > RVA_MAX_BATCH || w < 3 ||
-        h < 3 || ((w | h) & 1))
-        return rva_fail(ctx, RVA_ERR_ARG, "rva_motion_nv12_batch: bad argument");
+    if (!ctx || !y_ptrs || (nv12 && !uv_ptrs) || !pitches || !prev_blur || !blur_out || !counts || n <= 0 || n > RVA_MAX_BATCH ||
+        w < 3 || h < 3 || (nv12 && ((w | h) & 1)))
+        return rva_fail(ctx, RVA_ERR_ARG, "rva_motion_*_batch: bad argument");
     K5Args a{};
     for (int i = 0; i < n; ++i) {
-        if (!y_ptrs[i] || !uv_ptrs[i] || !blur_out[i] || pitches[i] < w) return rva_fail(ctx, RVA_ERR_ARG, "rva_motion_nv12_batch: bad surface %d", i);
-        a.y[i] = (const uint8_t *)y_ptrs[i]; a.uv[i] = (const uint8_t *)uv_ptrs[i];
+        if (!y_ptrs[i] || (nv12 && !uv_ptrs[i]) || !blur_out[i] || pitches[i] < (nv12 ? w : 3 * w))
+            return rva_fail(ctx, RVA_ERR_ARG, "rva_motion_*_batch: bad surface %d", i);
+        a.y[i] = (const uint8_t *)y_ptrs[i]; a.uv[i] = nv12 ? (const uint8_t *)uv_ptrs[i] : nullptr;
         a.prev[i] = (const uint8_t *)prev_blur[i]; a.out[i] = (uint8_t *)blur_out[i]; a.pitch[i] = pitches[i];
+        a.mask[i] = masks ? (const uint8_t *)masks[i] : nullptr;
     }
     a.w = w; a.h = h; a.counts = counts;
     hipStream_t s = (hipStream_t)stream_;
     k5_init<<<1, 64, 0, s>>>(counts, a, n);
     dim3 grid(rva_ceil_div(w, TW), rva_ceil_div(h, TH), n);
-    k5_motion<<<grid, 256, 0, s>>>(a);
+    if (nv12) k5_motion<true><<<grid, 256, 0, s>>>(a);
+    else k5_motion<false><<<grid, 256, 0, s>>>(a);
     RVA_HIP(ctx, hipGetLastError());
     return RVA_OK;
+}
+
+extern "C" int rva_motion_nv12_batch(rva_ctx *ctx, const void *const *y_ptrs, const void *const *uv_ptrs,
+                                     const int32_t *pitches, const void *const *prev_blur, void *const *blur_out, int n,
+                                     int w, int h, int32_t *counts, rva_stream_t stream)
+{
+    return motion_common(ctx, true, y_ptrs, uv_ptrs, pitches, nullptr, prev_blur, blur_out, n, w, h, counts, stream);
+}
+
+// masks[i] (may be NULL): ROI mask applied first, as apply_roi precedes the gate (pipeline.py:149-158)
+extern "C" int rva_motion_nv12_masked_batch(rva_ctx *ctx, const void *const *y_ptrs, const void *const *uv_ptrs,
+                                            const int32_t *pitches, const void *const *masks, const void *const *prev_blur,
+                                            void *const *blur_out, int n, int w, int h, int32_t *counts, rva_stream_t stream)
+{
+    return motion_common(ctx, true, y_ptrs, uv_ptrs, pitches, masks, prev_blur, blur_out, n, w, h, counts, stream);
+}
+
+// frames[i]: uint8 BGR [h][w][3] device images (e.g. the downsampled frames of rva_resize_nv12_to_bgr_batch)
+extern "C" int rva_motion_bgr_batch(rva_ctx *ctx, const void *const *frames, const int32_t *row_bytes,
+                                    const void *const *prev_blur, void *const *blur_out, int n, int w, int h,
+                                    int32_t *counts, rva_stream_t stream)
+{
+    return motion_common(ctx, false, frames, nullptr, row_bytes, nullptr, prev_blur, blur_out, n, w, h, counts, stream);
 }

@@ -30,6 +30,7 @@ struct K1Args {
     const uint8_t *p0[RVA_MAX_BATCH];  // Y plane (NV12) or BGR frame
     const uint8_t *p1[RVA_MAX_BATCH];  // interleaved UV plane (NV12)
     int32_t pitch[RVA_MAX_BATCH];      // bytes per row
+    const uint8_t *mask[RVA_MAX_BATCH]; // optional ROI mask uint8 [src_h][src_w] (0 = outside: pixel becomes BGR 0,0,0)
     int src_w, src_h, dst_w, dst_h, new_w, new_h, left, top;
     const int32_t *xofs; const int16_t *xw0, *xw1;
     const int32_t *yofs; const int16_t *yw0, *yw1;
@@ -84,7 +85,7 @@ __device__ __forceinline__ void store8(OutT *dst, const OutT *v, bool vec_ok, in
 }
 
 // ---- integer-ratio fast path -----------------------------------------------------------------
-template <int R, typename OutT, int PX>
+template <int R, typename OutT, int PX, bool MASK>
 __global__ void __launch_bounds__(256) k1_ratio(K1Args a)
 {
     const int img = blockIdx.y;
@@ -131,6 +132,16 @@ __global__ void __launch_bounds__(256) k1_ratio(K1Args a)
             const uint32_t d = (o & 4) ? w[o >> 3].y : w[o >> 3].x;
             return (int)((d >> ((o & 3) * 8)) & 0xffu);
         };
+        uint2 mw[ROWS][NW];
+        const uint8_t *mp = MASK ? a.mask[img] : nullptr;       // apply_roi: frame & mask (utils/frame_filter.py:43-50)
+        if (MASK && mp) {
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+                const uint2 *ms = reinterpret_cast<const uint2 *>(mp + (size_t)(sy0 + r) * a.src_w + xoff);
+#pragma unroll
+                for (int k = 0; k < NW; ++k) mw[r][k] = ms[k];
+            }
+        }
 #pragma unroll
         for (int i = 0; i < PX; ++i) {
             int b, g, r;
@@ -138,6 +149,7 @@ __global__ void __launch_bounds__(256) k1_ratio(K1Args a)
                 const int o = R * i + (R - 1) / 2;
                 const int uo = (o >> 1) << 1;
                 yuv2bgr(byte_at(yw[0], o), byte_at(uw[0], uo), byte_at(uw[0], uo + 1), b, g, r);
+                if (MASK && mp && byte_at(mw[0], o) == 0) b = g = r = 0;
             } else {
                 int sb = 2, sg = 2, sr = 2;  // (a + b + c + d + 2) >> 2
 #pragma unroll
@@ -148,6 +160,7 @@ __global__ void __launch_bounds__(256) k1_ratio(K1Args a)
                         const int uo = (o >> 1) << 1;
                         int tb, tg, tr;
                         yuv2bgr(byte_at(yw[rr], o), byte_at(uw[rr], uo), byte_at(uw[rr], uo + 1), tb, tg, tr);
+                        if (MASK && mp && byte_at(mw[rr], o) == 0) tb = tg = tr = 0;
                         sb += tb; sg += tg; sr += tr;
                     }
                 b = sb >> 2; g = sg >> 2; r = sr >> 2;
@@ -164,7 +177,9 @@ __global__ void __launch_bounds__(256) k1_ratio(K1Args a)
 }
 
 // ---- general path ----------------------------------------------------------------------------
-template <bool NV12, bool CLIP, typename OutT>
+// MODE: 0 = detector tensor (letterbox, x 1/255), 1 = clip tensor (stretch, mean/std), 2 = uint8 BGR HWC image
+// (stretch; the `downsample` stage of utils/frame_filter.py:53-57)
+template <bool NV12, int MODE, typename OutT>
 __global__ void __launch_bounds__(256) k1_generic(K1Args a)
 {
     const int img = blockIdx.y;
@@ -189,7 +204,9 @@ __global__ void __launch_bounds__(256) k1_generic(K1Args a)
         sy1 = min(max(s + 1, 0), a.src_h - 1);
         wb0 = a.yw0[cy]; wb1 = a.yw1[cy];
     }
+    const uint8_t *mp = a.mask[img];
     auto fetch = [&](int sy, int sx, int &b, int &g, int &r) {
+        if (mp && mp[(size_t)sy * a.src_w + sx] == 0) { b = g = r = 0; return; }   // apply_roi
         if constexpr (NV12) {
             const int Y = p0[(size_t)sy * pitch + sx];
             const uint8_t *u = p1 + (size_t)(sy >> 1) * pitch + ((sx >> 1) << 1);
@@ -221,35 +238,42 @@ __global__ void __launch_bounds__(256) k1_generic(K1Args a)
             };
             b = mix(b00, b01, b10, b11); g = mix(g00, g01, g10, g11); r = mix(r00, r01, r10, r11);
         }
-        if constexpr (CLIP) {
+        if constexpr (MODE == 2) {
+            if (i < nvalid) {
+                uint8_t *o8 = (uint8_t *)a.out + ((size_t)img * a.dst_h * a.dst_w + (size_t)oy * a.dst_w + ox + i) * 3;
+                o8[0] = (uint8_t)b; o8[1] = (uint8_t)g; o8[2] = (uint8_t)r;
+            }
+        } else if constexpr (MODE == 1) {
             vr[i] = norm_clip(r, 0, OutT()); vg[i] = norm_clip(g, 1, OutT()); vb[i] = norm_clip(b, 2, OutT());
         } else {
             vr[i] = norm_yolo(r, OutT()); vg[i] = norm_yolo(g, OutT()); vb[i] = norm_yolo(b, OutT());
         }
     }
+    if constexpr (MODE == 2) return;
     const bool vec_ok = (a.dst_w & 7) == 0;
     store8<OutT>(out, vr, vec_ok, nvalid);
     store8<OutT>(out + plane, vg, vec_ok, nvalid);
     store8<OutT>(out + 2 * plane, vb, vec_ok, nvalid);
 }
 
-template <typename OutT, int PX>
+template <typename OutT, int PX, bool MASK = false>
 bool launch_ratio(int R, dim3 grid, hipStream_t s, const K1Args &a)
 {
     switch (R) {
-        case 1: k1_ratio<1, OutT, PX><<<grid, 256, 0, s>>>(a); return true;
-        case 2: k1_ratio<2, OutT, PX><<<grid, 256, 0, s>>>(a); return true;
-        case 3: k1_ratio<3, OutT, PX><<<grid, 256, 0, s>>>(a); return true;
-        case 4: k1_ratio<4, OutT, PX><<<grid, 256, 0, s>>>(a); return true;
-        case 6: k1_ratio<6, OutT, PX><<<grid, 256, 0, s>>>(a); return true;
+        case 1: k1_ratio<1, OutT, PX, MASK><<<grid, 256, 0, s>>>(a); return true;
+        case 2: k1_ratio<2, OutT, PX, MASK><<<grid, 256, 0, s>>>(a); return true;
+        case 3: k1_ratio<3, OutT, PX, MASK><<<grid, 256, 0, s>>>(a); return true;
+        case 4: k1_ratio<4, OutT, PX, MASK><<<grid, 256, 0, s>>>(a); return true;
+        case 6: k1_ratio<6, OutT, PX, MASK><<<grid, 256, 0, s>>>(a); return true;
         default: return false;
     }
 }
 
-int preprocess_common(rva_ctx *ctx, bool nv12, bool clip, const void *const *p0, const void *const *p1,
+int preprocess_common(rva_ctx *ctx, bool nv12, int mode, const void *const *p0, const void *const *p1,
                       const int32_t *pitches, int n, int src_w, int src_h, void *out, int out_dtype, int dst_w,
-                      int dst_h, rva_letterbox *meta_out, hipStream_t stream)
+                      int dst_h, rva_letterbox *meta_out, hipStream_t stream, const void *const *masks = nullptr)
 {
+    const bool clip = mode != 0;   // modes 1 and 2 stretch to the full target, no letterbox border
     if (!ctx) return RVA_ERR_ARG;
     if (!p0 || (nv12 && !p1) || !pitches || n <= 0 || n > RVA_MAX_BATCH || !out || src_w <= 0 || src_h <= 0 ||
         dst_w <= 0 || dst_h <= 0)
@@ -272,6 +296,7 @@ int preprocess_common(rva_ctx *ctx, bool nv12, bool clip, const void *const *p0,
         a.p0[i] = (const uint8_t *)p0[i];
         a.p1[i] = nv12 ? (const uint8_t *)p1[i] : nullptr;
         a.pitch[i] = pitches[i];
+        a.mask[i] = masks ? (const uint8_t *)masks[i] : nullptr;
         if (!p0[i] || (nv12 && !p1[i]) || pitches[i] < (nv12 ? src_w : 3 * src_w))
             return rva_fail(ctx, RVA_ERR_ARG, "preprocess: surface %d has a null plane or a short pitch", i);
         aligned8 = aligned8 && ((uintptr_t)p0[i] % 8 == 0) && (!nv12 || (uintptr_t)p1[i] % 8 == 0) && pitches[i] % 8 == 0;
@@ -279,12 +304,18 @@ int preprocess_common(rva_ctx *ctx, bool nv12, bool clip, const void *const *p0,
     a.src_w = src_w; a.src_h = src_h; a.dst_w = dst_w; a.dst_h = dst_h;
     a.new_w = m.new_w; a.new_h = m.new_h; a.left = m.pad_left; a.top = m.pad_top;
     a.out = out;
-    const size_t osz = out_dtype == RVA_F16 ? 2 : 4;
+    bool any_mask = false, mask_aligned = true;
+    for (int i = 0; i < n; ++i) {
+        any_mask = any_mask || a.mask[i];
+        mask_aligned = mask_aligned && ((uintptr_t)a.mask[i] % 8 == 0);
+    }
+    mask_aligned = mask_aligned && src_w % 8 == 0;
+    const size_t osz = mode == 2 ? 1 : (out_dtype == RVA_F16 ? 2 : 4);
     const bool out_aligned = ((uintptr_t)out % 16 == 0) && ((dst_w * osz) % 16 == 0);
 
     // integer-ratio fast path
     const int R = src_w / m.new_w;
-    const bool ratio_ok = nv12 && !clip && aligned8 && out_aligned && R * m.new_w == src_w && R * m.new_h == src_h &&
+    const bool ratio_ok = nv12 && !clip && aligned8 && out_aligned && (!any_mask || mask_aligned) && R * m.new_w == src_w && R * m.new_h == src_h &&
                           (dst_w % 8 == 0) && (m.new_w % 8 == 0) && (m.pad_left % 8 == 0);
     if (ratio_ok) {
         // 16 pixels per lane (16-byte loads) when the geometry is 16-aligned and every surface 16-byte aligned
@@ -293,11 +324,13 @@ int preprocess_common(rva_ctx *ctx, bool nv12, bool clip, const void *const *p0,
         bool aligned16 = true;
         for (int i = 0; i < n; ++i)
             aligned16 = aligned16 && ((uintptr_t)p0[i] % 16 == 0) && ((uintptr_t)p1[i] % 16 == 0) && pitches[i] % 16 == 0;
-        const bool px16 = px_env == 16 && aligned16   /* measured slower than 8 px/lane (profiles/r01_k1_variants.txt): opt-in only */ && dst_w % 16 == 0 && m.new_w % 16 == 0 && m.pad_left % 16 == 0 && R <= 3 &&
+        const bool px16 = !any_mask && px_env == 16 && aligned16   /* measured slower than 8 px/lane (profiles/r01_k1_variants.txt): opt-in only */ && dst_w % 16 == 0 && m.new_w % 16 == 0 && m.pad_left % 16 == 0 && R <= 3 &&
                           out_dtype == RVA_F16;
         const int PXv = px16 ? 16 : 8;
         dim3 grid(rva_ceil_div((dst_w / PXv) * dst_h, 256), n);
-        const bool ok = px16 ? launch_ratio<__half, 16>(R, grid, stream, a)
+        const bool ok = any_mask ? (out_dtype == RVA_F16 ? launch_ratio<__half, 8, true>(R, grid, stream, a)
+                                                          : launch_ratio<float, 8, true>(R, grid, stream, a))
+                      : px16 ? launch_ratio<__half, 16>(R, grid, stream, a)
                              : (out_dtype == RVA_F16 ? launch_ratio<__half, 8>(R, grid, stream, a) : launch_ratio<float, 8>(R, grid, stream, a));
         if (ok) {
             RVA_HIP(ctx, hipGetLastError());
@@ -311,18 +344,19 @@ int preprocess_common(rva_ctx *ctx, bool nv12, bool clip, const void *const *p0,
     if (rc != RVA_OK) return rc;
     a.xofs = tx.ofs; a.xw0 = tx.w0; a.xw1 = tx.w1;
     a.yofs = ty.ofs; a.yw0 = ty.w0; a.yw1 = ty.w1;
-    if (!out_aligned && (dst_w % 8 == 0))  // vector stores need 16-byte rows
+    if (mode != 2 && !out_aligned && (dst_w % 8 == 0))  // vector stores need 16-byte rows
         return rva_fail(ctx, RVA_ERR_ARG, "output tensor must be 16-byte aligned");
     dim3 grid(rva_ceil_div(rva_ceil_div(dst_w, 8) * dst_h, 256), n);
-#define RVA_LAUNCH_GENERIC(NV, CL)                                                         \
+#define RVA_LAUNCH_GENERIC(NV, MD)                                                         \
     do {                                                                                   \
-        if (out_dtype == RVA_F16) k1_generic<NV, CL, __half><<<grid, 256, 0, stream>>>(a); \
-        else k1_generic<NV, CL, float><<<grid, 256, 0, stream>>>(a);                       \
+        if (out_dtype == RVA_F16) k1_generic<NV, MD, __half><<<grid, 256, 0, stream>>>(a); \
+        else k1_generic<NV, MD, float><<<grid, 256, 0, stream>>>(a);                       \
     } while (0)
-    if (nv12 && clip) RVA_LAUNCH_GENERIC(true, true);
-    else if (nv12) RVA_LAUNCH_GENERIC(true, false);
-    else if (clip) RVA_LAUNCH_GENERIC(false, true);
-    else RVA_LAUNCH_GENERIC(false, false);
+    if (mode == 2) { if (nv12) RVA_LAUNCH_GENERIC(true, 2); else RVA_LAUNCH_GENERIC(false, 2); }
+    else if (nv12 && clip) RVA_LAUNCH_GENERIC(true, 1);
+    else if (nv12) RVA_LAUNCH_GENERIC(true, 0);
+    else if (clip) RVA_LAUNCH_GENERIC(false, 1);
+    else RVA_LAUNCH_GENERIC(false, 0);
 #undef RVA_LAUNCH_GENERIC
     RVA_HIP(ctx, hipGetLastError());
     return RVA_OK;
@@ -336,7 +370,7 @@ int rva_preprocess_nv12_batch(rva_ctx *ctx, const void *const *y_ptrs, const voi
                               const int32_t *pitches, int n, int src_w, int src_h, void *out, int out_dtype,
                               int dst_w, int dst_h, rva_letterbox *meta_out, rva_stream_t stream)
 {
-    return preprocess_common(ctx, true, false, y_ptrs, uv_ptrs, pitches, n, src_w, src_h, out, out_dtype, dst_w, dst_h,
+    return preprocess_common(ctx, true, 0, y_ptrs, uv_ptrs, pitches, n, src_w, src_h, out, out_dtype, dst_w, dst_h,
                              meta_out, (hipStream_t)stream);
 }
 
@@ -344,7 +378,7 @@ int rva_preprocess_bgr_batch(rva_ctx *ctx, const void *const *frames, const int3
                              int src_h, void *out, int out_dtype, int dst_w, int dst_h, rva_letterbox *meta_out,
                              rva_stream_t stream)
 {
-    return preprocess_common(ctx, false, false, frames, nullptr, row_bytes, n, src_w, src_h, out, out_dtype, dst_w, dst_h,
+    return preprocess_common(ctx, false, 0, frames, nullptr, row_bytes, n, src_w, src_h, out, out_dtype, dst_w, dst_h,
                              meta_out, (hipStream_t)stream);
 }
 
@@ -352,15 +386,33 @@ int rva_preprocess_clip_nv12_batch(rva_ctx *ctx, const void *const *y_ptrs, cons
                                    const int32_t *pitches, int n, int src_w, int src_h, void *out, int out_dtype,
                                    int dst_w, int dst_h, rva_stream_t stream)
 {
-    return preprocess_common(ctx, true, true, y_ptrs, uv_ptrs, pitches, n, src_w, src_h, out, out_dtype, dst_w, dst_h,
+    return preprocess_common(ctx, true, 1, y_ptrs, uv_ptrs, pitches, n, src_w, src_h, out, out_dtype, dst_w, dst_h,
                              nullptr, (hipStream_t)stream);
 }
 
 int rva_preprocess_clip_bgr_batch(rva_ctx *ctx, const void *const *frames, const int32_t *row_bytes, int n, int src_w,
                                   int src_h, void *out, int out_dtype, int dst_w, int dst_h, rva_stream_t stream)
 {
-    return preprocess_common(ctx, false, true, frames, nullptr, row_bytes, n, src_w, src_h, out, out_dtype, dst_w, dst_h,
+    return preprocess_common(ctx, false, 1, frames, nullptr, row_bytes, n, src_w, src_h, out, out_dtype, dst_w, dst_h,
                              nullptr, (hipStream_t)stream);
+}
+
+// ---- ROI mask + downsample in front of the detector ------------------------------------------
+int rva_preprocess_nv12_masked_batch(rva_ctx *ctx, const void *const *y_ptrs, const void *const *uv_ptrs,
+                                     const int32_t *pitches, const void *const *masks, int n, int src_w, int src_h,
+                                     void *out, int out_dtype, int dst_w, int dst_h, rva_letterbox *meta_out,
+                                     rva_stream_t stream)
+{
+    return preprocess_common(ctx, true, 0, y_ptrs, uv_ptrs, pitches, n, src_w, src_h, out, out_dtype, dst_w, dst_h, meta_out,
+                             (hipStream_t)stream, masks);
+}
+
+int rva_resize_nv12_to_bgr_batch(rva_ctx *ctx, const void *const *y_ptrs, const void *const *uv_ptrs,
+                                 const int32_t *pitches, const void *const *masks, int n, int src_w, int src_h,
+                                 void *out_bgr, int dst_w, int dst_h, rva_stream_t stream)
+{
+    return preprocess_common(ctx, true, 2, y_ptrs, uv_ptrs, pitches, n, src_w, src_h, out_bgr, RVA_F16, dst_w, dst_h, nullptr,
+                             (hipStream_t)stream, masks);
 }
 
 }  // extern "C"

@@ -40,6 +40,7 @@ struct rva_tracker {
     int32_t *d_slot = nullptr;    // [S] per-tick: slot / active
     int32_t *d_offs = nullptr;    // [S+1]
     int32_t *d_gidx = nullptr;    // [S]
+    double *d_bscale = nullptr;   // [S] box scale of _rescale_detections (1.0 = no downsample)
     // pinned host staging
     int32_t *h_slot = nullptr, *h_offs = nullptr;
     void *h_read[2] = {nullptr, nullptr};   // pinned snapshot slots
@@ -60,6 +61,7 @@ struct K4Args {
                                              // no staging buffer to race with, and graph-capturable)
     // f32 source (post-process outputs)
     const float4 *boxes32; const float *scores32; const int32_t *cls32; const int32_t *counts32; int max_det;
+    const double *bscale;   // per-stream multiplier applied to the widened box (pipeline.py:237)
     double filter_thr;
     // f64 source (host API)
     const int32_t *offs; const double *boxes64; const double *conf64; const int64_t *cls64;
@@ -135,6 +137,8 @@ __global__ void __launch_bounds__(64) k4_update(K4Args a)
             const size_t o = (size_t)slot * a.max_det + d;
             const float4 f = a.boxes32[o];
             b0 = (double)f.x; b1 = (double)f.y; b2 = (double)f.z; b3 = (double)f.w;  // exact widening
+            const double bs = a.bscale[s];
+            if (bs != 1.0) { b0 *= bs; b1 *= bs; b2 *= bs; b3 *= bs; }              // _rescale_detections (float64 multiply)
             dconf = (double)a.scores32[o];
             dcls = a.cls32[o];
             if (!(dconf >= a.filter_thr)) continue;  // filter_detections, pipeline.py:182 (wave-uniform)
@@ -282,6 +286,11 @@ int rva_tracker_create(rva_ctx *ctx, int n_streams, int capacity, int max_age, d
     RVA_HIP(ctx, hipMalloc(&t->d_slot, n_streams * 4));
     RVA_HIP(ctx, hipMalloc(&t->d_offs, (n_streams + 1) * 4));
     RVA_HIP(ctx, hipMalloc(&t->d_gidx, n_streams * 4));
+    RVA_HIP(ctx, hipMalloc(&t->d_bscale, n_streams * 8));
+    {
+        std::vector<double> ones(n_streams, 1.0);
+        RVA_HIP(ctx, hipMemcpy(t->d_bscale, ones.data(), n_streams * 8, hipMemcpyHostToDevice));
+    }
     RVA_HIP(ctx, hipHostMalloc(&t->h_slot, n_streams * 4));
     RVA_HIP(ctx, hipHostMalloc(&t->h_offs, (n_streams + 1) * 4));
     RVA_HIP(ctx, hipEventCreateWithFlags(&t->staged, hipEventDisableTiming));
@@ -305,7 +314,7 @@ void rva_tracker_destroy(rva_tracker *t)
     (void)hipSetDevice(t->ctx->device);
     (void)hipDeviceSynchronize();
     void *dev[] = {t->id, t->box, t->conf, t->cls, t->age, t->hits, t->last_det, t->n_tracks, t->n_new, t->next_id, t->id_ticket, t->flags,
-                   t->d_slot, t->d_offs, t->d_gidx};
+                   t->d_slot, t->d_offs, t->d_gidx, t->d_bscale};
     for (void *p : dev) (void)hipFree(p);
     void *host[] = {t->h_slot, t->h_offs, t->h_read[0], t->h_read[1]};
     for (int i = 0; i < 2; ++i) if (t->snap_done[i]) (void)hipEventDestroy(t->snap_done[i]);
@@ -330,6 +339,7 @@ int rva_tracker_update_f32(rva_tracker *t, const int32_t *slot_of_stream, const 
         return rva_fail(t->ctx, RVA_ERR_ARG, "rva_tracker_update_f32: detection arrays missing");
     a.boxes32 = (const float4 *)boxes; a.scores32 = scores; a.cls32 = cls; a.counts32 = counts; a.max_det = max_det;
     a.filter_thr = filter_thr;
+    a.bscale = t->d_bscale;
     return launch_update(t, a, false, stream);
 }
 
@@ -347,6 +357,14 @@ int rva_tracker_update_f64(rva_tracker *t, const int32_t *active, const int32_t 
     K4Args a{};
     a.slot = t->d_slot; a.offs = t->d_offs; a.boxes64 = boxes; a.conf64 = conf; a.cls64 = cls;
     return launch_update(t, a, true, stream);
+}
+
+int rva_tracker_set_box_scale(rva_tracker *t, const double *scales)
+{
+    if (!t || !scales) return RVA_ERR_ARG;
+    RVA_HIP(t->ctx, hipDeviceSynchronize());
+    RVA_HIP(t->ctx, hipMemcpy(t->d_bscale, scales, (size_t)t->n_streams * 8, hipMemcpyHostToDevice));
+    return RVA_OK;
 }
 
 int32_t *rva_tracker_new_counts(rva_tracker *t) { return t ? t->n_new : nullptr; }

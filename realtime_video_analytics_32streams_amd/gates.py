@@ -8,7 +8,12 @@ pixel work on the GPU:
     (pipeline.py:107-116, 165-170, 242-262).
 A gated-out frame is a *skipped* frame: ``tracker.update(name, [])`` semantics (pipeline.py:214-222),
 which :class:`~.pipeline.TickPipeline` expresses as ``process[i] = False``.
-Not built this round: ROI polygon masks and ``downsample_ratio`` (the other two gates of 8f-2).
+  * :func:`rasterize_polygons` -- the mask of ``apply_roi`` (utils/frame_filter.py:43-50); the mask is applied on
+    the GPU inside K1 / K5 (``Nv12Surface.mask``).  cv2.fillPoly's exact edge rule is unpinned (OpenCV absent):
+    interior by the even-odd rule at integer pixel coordinates plus every pixel on a polygon edge; exact for
+    axis-aligned rectangles, which fillPoly fills inclusively.
+  * ``downsample_ratio`` (utils/frame_filter.py:53-57) is ``ops.resize_nv12_to_bgr`` + the per-stream box scale of
+    ``DeviceTracker.set_box_scale`` (``_rescale_detections``, pipeline.py:224-240); wired in ``TickPipeline``.
 """
 from __future__ import annotations
 
@@ -22,6 +27,33 @@ from . import ops
 from .config import StreamConfig
 
 
+def rasterize_polygons(polygons, width: int, height: int):
+    """uint8 [height, width] mask, 255 inside any polygon (see module docstring for the edge rule)."""
+    import numpy as np
+    mask = np.zeros((height, width), np.uint8)
+    ys, xs = np.mgrid[0:height, 0:width]
+    for poly in polygons or []:
+        pts = np.asarray(poly, np.int64)
+        n = len(pts)
+        if n == 0:
+            continue
+        inside = np.zeros((height, width), bool)
+        edge = np.zeros((height, width), bool)
+        for i in range(n):
+            (x0, y0), (x1, y1) = pts[i], pts[(i + 1) % n]
+            if y0 != y1:      # even-odd crossing test, half-open in y
+                cond = ((y0 <= ys) & (ys < y1)) | ((y1 <= ys) & (ys < y0))
+                t = (xs - x0) * (y1 - y0) - (x1 - x0) * (ys - y0)
+                inside ^= cond & ((t < 0) == (y1 > y0))
+            # pixels on the edge itself (fillPoly draws the outline)
+            cross = (xs - x0) * (y1 - y0) - (ys - y0) * (x1 - x0)
+            on = (np.abs(cross) * 2 <= max(abs(x1 - x0), abs(y1 - y0))) & (xs >= min(x0, x1)) & (xs <= max(x0, x1)) & \
+                 (ys >= min(y0, y1)) & (ys <= max(y0, y1))
+            edge |= on
+        mask[inside | edge] = 255
+    return mask
+
+
 class MotionGate:
     def __init__(self, n_streams: int, width: int, height: int, thresholds: Sequence[float], ctx: Optional[N.Context] = None):
         self.ctx = ctx or ops.context()
@@ -33,22 +65,30 @@ class MotionGate:
         self._flip = [0] * n_streams
         self.counts = torch.zeros(n_streams, dtype=torch.int32, device=dev)
 
-    def step(self, surfaces: Sequence[Optional[ops.Nv12Surface]]) -> List[bool]:
-        """``surfaces[i]`` is stream i's frame of this tick (None: no frame).  Returns should_process per stream
-        (True for the first frame of a stream, frame_filter.py:33-35).  One host sync (n int32)."""
+    def step(self, surfaces: Sequence) -> List[bool]:
+        """``surfaces[i]`` is stream i's frame_for_detection of this tick: an ``Nv12Surface`` (its ``mask`` is
+        honoured), a uint8 BGR device tensor [h, w, 3] (downsampled frame), or None (no frame).  Returns
+        should_process per stream (True for a stream's first frame, frame_filter.py:33-35).  One host sync."""
         idx = [i for i, s in enumerate(surfaces) if s is not None]
         out = [True] * len(surfaces)
         if not idx:
             return out
-        yp, _a = N.ptr_array([surfaces[i].y.data_ptr() for i in idx])
-        up, _b = N.ptr_array([surfaces[i].uv.data_ptr() for i in idx])
-        pp, _c = N.i32_array([surfaces[i].pitch for i in idx])
         prev, _d = N.ptr_array([self._blur[i][self._flip[i] ^ 1].data_ptr() if self._have_prev[i] else 0 for i in idx])
         cur, _e = N.ptr_array([self._blur[i][self._flip[i]].data_ptr() for i in idx])
-        rc = N.lib().rva_motion_nv12_batch(self.ctx.handle, yp, up, pp, prev, cur, len(idx), self.w, self.h,
-                                           C.c_void_p(self.counts.data_ptr()),
-                                           C.c_void_p(torch.cuda.current_stream().cuda_stream))
-        self.ctx.check(rc, "rva_motion_nv12_batch")
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        if isinstance(surfaces[idx[0]], ops.Nv12Surface):
+            yp, _a = N.ptr_array([surfaces[i].y.data_ptr() for i in idx])
+            up, _b = N.ptr_array([surfaces[i].uv.data_ptr() for i in idx])
+            pp, _c = N.i32_array([surfaces[i].pitch for i in idx])
+            mp, _m = N.ptr_array([surfaces[i].mask.data_ptr() if surfaces[i].mask is not None else 0 for i in idx])
+            rc = N.lib().rva_motion_nv12_masked_batch(self.ctx.handle, yp, up, pp, mp, prev, cur, len(idx), self.w, self.h,
+                                                      C.c_void_p(self.counts.data_ptr()), stream)
+        else:
+            fp, _a = N.ptr_array([surfaces[i].data_ptr() for i in idx])
+            rb, _b = N.i32_array([int(surfaces[i].stride(0)) for i in idx])
+            rc = N.lib().rva_motion_bgr_batch(self.ctx.handle, fp, rb, prev, cur, len(idx), self.w, self.h,
+                                              C.c_void_p(self.counts.data_ptr()), stream)
+        self.ctx.check(rc, "rva_motion_*_batch")
         cnt = self.counts[:len(idx)].cpu().tolist()
         for k, i in enumerate(idx):
             if self._have_prev[i]:

@@ -42,6 +42,7 @@ class Nv12Surface:
     uv: torch.Tensor   # uint8 [h/2, pitch]
     width: int
     height: int
+    mask: Optional[torch.Tensor] = None   # optional ROI mask uint8 [h, w] (0 = outside), see gates.rasterize_polygons
 
     @property
     def pitch(self) -> int:
@@ -83,12 +84,36 @@ def preprocess_nv12(surfaces: Sequence[Nv12Surface], dst_hw=(640, 640), half: bo
         if clip:
             rc = L.rva_preprocess_clip_nv12_batch(ctx.handle, yp, up, pp, len(chunk), w, h, optr,
                                                   N.RVA_F16 if half else N.RVA_F32, dst_hw[1], dst_hw[0], _stream_ptr())
+        elif any(s.mask is not None for s in chunk):          # apply_roi in front of the resize
+            mp, _k4 = N.ptr_array([s.mask.data_ptr() if s.mask is not None else 0 for s in chunk])
+            rc = L.rva_preprocess_nv12_masked_batch(ctx.handle, yp, up, pp, mp, len(chunk), w, h, optr,
+                                                    N.RVA_F16 if half else N.RVA_F32, dst_hw[1], dst_hw[0], C.byref(meta),
+                                                    _stream_ptr())
         else:
             rc = L.rva_preprocess_nv12_batch(ctx.handle, yp, up, pp, len(chunk), w, h, optr,
                                              N.RVA_F16 if half else N.RVA_F32, dst_hw[1], dst_hw[0], C.byref(meta),
                                              _stream_ptr())
         ctx.check(rc, "rva_preprocess_nv12_batch")
     return (out, None) if clip else (out, meta)
+
+
+def resize_nv12_to_bgr(surfaces: Sequence[Nv12Surface], dst_wh: Tuple[int, int], out: Optional[torch.Tensor] = None,
+                       ctx: Optional[N.Context] = None) -> torch.Tensor:
+    """apply_roi (if a surface carries a mask) + downsample (utils/frame_filter.py:43-57): uint8 BGR images
+    ``[n, dst_h, dst_w, 3]`` on the device, ready for :func:`preprocess_bgr`."""
+    ctx = ctx or context()
+    n, (dw, dh) = len(surfaces), dst_wh
+    w, h = surfaces[0].width, surfaces[0].height
+    if out is None:
+        out = torch.empty((n, dh, dw, 3), dtype=torch.uint8, device=surfaces[0].y.device)
+    yp, _k1 = N.ptr_array([s.y.data_ptr() for s in surfaces])
+    up, _k2 = N.ptr_array([s.uv.data_ptr() for s in surfaces])
+    pp, _k3 = N.i32_array([s.pitch for s in surfaces])
+    mp, _k4 = N.ptr_array([s.mask.data_ptr() if s.mask is not None else 0 for s in surfaces])
+    rc = N.lib().rva_resize_nv12_to_bgr_batch(ctx.handle, yp, up, pp, mp, n, w, h, C.c_void_p(out.data_ptr()), dw, dh,
+                                              _stream_ptr())
+    ctx.check(rc, "rva_resize_nv12_to_bgr_batch")
+    return out
 
 
 def preprocess_bgr(frames: Sequence[torch.Tensor], dst_hw=(640, 640), half: bool = True,
@@ -259,6 +284,11 @@ class DeviceTracker:
                                             C.c_void_p(dk.data_ptr()), _stream_ptr())
         self.ctx.check(rc, "rva_tracker_update_f64")
         self._keepalive = (db, dc, dk)
+
+    def set_box_scale(self, scales: Sequence[float]) -> None:
+        """_rescale_detections (pipeline.py:224-240): per-stream float64 multiplier for boxes fed by update_from_post."""
+        arr = (C.c_double * self.n_streams)(*[float(v) for v in scales])
+        self.ctx.check(N.lib().rva_tracker_set_box_scale(self.handle, arr), "rva_tracker_set_box_scale")
 
     def new_counts_tensor(self) -> torch.Tensor:
         """Zero-copy int32[n_streams] view of the device new-track counts of the last update."""

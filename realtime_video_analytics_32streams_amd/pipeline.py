@@ -28,7 +28,7 @@ import torch
 from . import ops
 from .config import PipelineConfig, StreamConfig
 from .detector import HipYoloDetector, create_detector
-from .gates import AdaptiveFps, MotionGate
+from .gates import AdaptiveFps, MotionGate, rasterize_polygons
 from .tracker import IouTracker, Track
 from .video_stream import FramePacket, open_stream
 
@@ -77,6 +77,43 @@ class TickPipeline:
         self.adaptive = [AdaptiveFps(s) for s in self.streams]
         self._motion: Optional[MotionGate] = None
         self._motion_on = [bool(s.motion_filter) for s in self.streams]
+        self._roi_masks: Dict[int, torch.Tensor] = {}          # stream index -> device mask (built at the first frame)
+        ratios = {float(s.downsample_ratio) for s in self.streams}
+        if len(ratios) > 1 and any(r < 0.999 for r in ratios):
+            raise NotImplementedError("TickPipeline batches one geometry per tick: use the same downsample_ratio on all streams")
+        self.downsample_ratio = ratios.pop() if ratios else 1.0
+        if self.downsample_ratio < 0.999:                       # _rescale_detections, pipeline.py:224-240
+            scale = 1.0 / max(self.downsample_ratio, 1e-6)
+            tracker.device_tracker.set_box_scale([scale] * tracker.device_tracker.n_streams)
+
+    def _frames_for_detection(self, packets: Sequence[Optional[FramePacket]]) -> List[Optional[FramePacket]]:
+        """apply_roi -> downsample (pipeline.py:148-154): returns packets whose ``frame`` is what the reference
+        calls ``frame_for_detection`` (masked surface, or the downsampled BGR image)."""
+        need_roi = any(s.roi_polygons for s in self.streams)
+        if not need_roi and self.downsample_ratio >= 0.999:
+            return list(packets)
+        out: List[Optional[FramePacket]] = []
+        live = []
+        for i, p in enumerate(packets):
+            if p is None or not isinstance(p.frame, ops.Nv12Surface):
+                out.append(p)
+                continue
+            f = p.frame
+            if self.streams[i].roi_polygons:
+                if i not in self._roi_masks:
+                    m = rasterize_polygons(self.streams[i].roi_polygons, f.width, f.height)
+                    self._roi_masks[i] = torch.from_numpy(m).to(f.y.device)
+                f = ops.Nv12Surface(f.y, f.uv, f.width, f.height, mask=self._roi_masks[i])
+            out.append(FramePacket(stream=p.stream, frame=f, frame_id=p.frame_id, timestamp=p.timestamp))
+            live.append(i)
+        if self.downsample_ratio < 0.999 and live:
+            f0 = out[live[0]].frame
+            dw, dh = int(f0.width * self.downsample_ratio), int(f0.height * self.downsample_ratio)
+            small = ops.resize_nv12_to_bgr([out[i].frame for i in live], (dw, dh), ctx=self.detector.ctx)
+            for k, i in enumerate(live):
+                p = out[i]
+                out[i] = FramePacket(stream=p.stream, frame=small[k], frame_id=p.frame_id, timestamp=p.timestamp)
+        return out
 
     def _gate(self, packets: Sequence[Optional[FramePacket]]) -> List[bool]:
         """should-process decision per stream, in the reference's order: motion gate (pipeline.py:156-163), then
@@ -85,13 +122,12 @@ class TickPipeline:
         n = len(packets)
         motion_ok = [True] * n
         if any(self._motion_on):
-            surf = [p.frame if (p is not None and self._motion_on[i] and isinstance(p.frame, ops.Nv12Surface)) else None
-                    for i, p in enumerate(packets)]
+            surf = [p.frame if (p is not None and self._motion_on[i]) else None for i, p in enumerate(packets)]
             first = next((f for f in surf if f is not None), None)
             if first is not None:
                 if self._motion is None:
-                    self._motion = MotionGate(n, first.width, first.height, [s.motion_threshold for s in self.streams],
-                                              ctx=self.detector.ctx)
+                    fw, fh = (first.width, first.height) if isinstance(first, ops.Nv12Surface) else (int(first.shape[1]), int(first.shape[0]))
+                    self._motion = MotionGate(n, fw, fh, [s.motion_threshold for s in self.streams], ctx=self.detector.ctx)
                 motion_ok = self._motion.step(surf)
         out = []
         for i, p in enumerate(packets):
@@ -133,7 +169,7 @@ class TickPipeline:
 
     def tick(self, process: Optional[Sequence[bool]] = None) -> TickResult:
         t0 = time.perf_counter()
-        packets = [src.next_packet() for src in self.sources]
+        packets = self._frames_for_detection([src.next_packet() for src in self.sources])
         if process is None and (any(self._motion_on) or any(a.enabled for a in self.adaptive)):
             process = self._gate(packets)
         post = self.enqueue(packets, process)

@@ -82,3 +82,96 @@ def test_pipeline_applies_motion_and_adaptive_gates():
     assert per_stream["moving"] >= 6                # synthetic rectangles move every tick (> 1 % of the pixels)
     # random-weight detector finds nothing -> the idle stream drops to every 3rd frame after 2 idle frames
     assert 1 <= per_stream["idle"] < 8 and pipe.adaptive[2].process_every == 3
+
+
+def test_rasterize_polygons_rectangles_are_inclusive():
+    from realtime_video_analytics_32streams_amd.gates import rasterize_polygons
+    m = rasterize_polygons([[(2, 1), (7, 1), (7, 4), (2, 4)], [(0, 0), (1, 0), (1, 1), (0, 1)]], 10, 6)
+    want = np.zeros((6, 10), np.uint8); want[1:5, 2:8] = 255; want[0:2, 0:2] = 255
+    assert np.array_equal(m, want)
+    assert rasterize_polygons([], 4, 3).sum() == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wh", [(1920, 1080), (1000, 700)], ids=["ratio-path", "generic-path"])
+def test_preprocess_with_roi_mask_matches_oracle(wh):
+    import torch
+    from oracle import oracle as orc
+    from realtime_video_analytics_32streams_amd import ops, synth
+    from realtime_video_analytics_32streams_amd.gates import rasterize_polygons
+    w, h = wh
+    y, uv = synth.make_nv12(11, w, h, ((w + 255) // 256) * 256)
+    mask = rasterize_polygons([[(w // 8, h // 6), (w * 3 // 4, h // 5), (w * 2 // 3, h * 5 // 6), (w // 5, h * 3 // 4)]], w, h)
+    s_m = ops.Nv12Surface.from_numpy(y, uv, w, h); s_m.mask = torch.from_numpy(mask).cuda()
+    s_0 = ops.Nv12Surface.from_numpy(y, uv, w, h)
+    out, meta = ops.preprocess_nv12([s_m, s_0], (640, 640), half=True)
+    bgr = orc.nv12_to_bgr(y, uv, w, h)
+    masked = bgr & (mask[..., None] // 255 * 255)            # cv2.bitwise_and(frame, frame, mask=mask)
+    want_m, _ = orc.preprocess_bgr(masked, 640, 640, True)
+    want_0, _ = orc.preprocess_bgr(bgr, 640, 640, True)
+    got = out.cpu().numpy()
+    assert np.array_equal(got[0].view(np.uint16), want_m.view(np.uint16))
+    assert np.array_equal(got[1].view(np.uint16), want_0.view(np.uint16))      # an unmasked stream in the same launch
+
+
+@pytest.mark.gpu
+def test_downsample_stage_and_box_rescale_match_oracle():
+    import torch
+    from oracle import oracle as orc
+    from realtime_video_analytics_32streams_amd import _native as N, ops, synth
+    w, h, ratio = 1920, 1080, 0.6
+    dw, dh = int(w * ratio), int(h * ratio)
+    y, uv = synth.make_nv12(12, w, h, 2048)
+    surf = ops.Nv12Surface.from_numpy(y, uv, w, h)
+    small = ops.resize_nv12_to_bgr([surf], (dw, dh))
+    want_small = orc.resize_linear(orc.nv12_to_bgr(y, uv, w, h), dw, dh)       # downsample(): cv2.resize INTER_LINEAR
+    assert np.array_equal(small[0].cpu().numpy(), want_small)
+    out, meta = ops.preprocess_bgr([small[0]], (640, 640), half=True)
+    want, m = orc.preprocess_bgr(want_small, 640, 640, True)
+    assert meta.as_meta() == m and np.array_equal(out.cpu().numpy()[0].view(np.uint16), want.view(np.uint16))
+    # _rescale_detections: float64 multiply by 1/max(ratio,1e-6) on the way into the tracker
+    scale = 1.0 / max(ratio, 1e-6)
+    head = np.ascontiguousarray(synth.make_head(3, n_obj=10).T)
+    post = ops.postprocess(torch.from_numpy(head).cuda()[None], 0.25, 0.45, None, [N.letterbox(dw, dh, 640, 640)])
+    trk = ops.DeviceTracker(1, 30, 0.5, 1, capacity=128)
+    trk.set_box_scale([scale])
+    trk.update_from_post([0], post, 0.25)
+    trk.assign_ids()
+    tab = trk.read(0)
+    ref = orc.postprocess(head, 0.25, 0.45, None, (dw, dh))
+    ref_boxes = ref["boxes"].astype(np.float64) * scale
+    otr = orc.Tracker(1, 30, 0.5, 1)
+    keep = ref["conf"].astype(np.float64) >= 0.25
+    wtab = otr.update(0, ref_boxes[keep], ref["conf"].astype(np.float64)[keep], ref["cls"].astype(np.int64)[keep])
+    assert orc.table_of(tab) == orc.table_of(wtab)
+
+
+@pytest.mark.gpu
+def test_pipeline_with_roi_and_downsample_runs_reference_order():
+    import torch
+    from oracle import oracle as orc
+    from realtime_video_analytics_32streams_amd import ops
+    from realtime_video_analytics_32streams_amd.config import DetectorConfig, TrackerConfig
+    from realtime_video_analytics_32streams_amd.detector import HipYoloDetector
+    from realtime_video_analytics_32streams_amd.pipeline import TickPipeline
+    from realtime_video_analytics_32streams_amd.tracker import IouTracker
+    from realtime_video_analytics_32streams_amd.video_stream import SyntheticNv12Stream
+    roi = [[(100, 50), (1700, 80), (1600, 1000), (200, 900)]]
+    streams = [StreamConfig(name=f"cam{i}", url="synthetic://1920x1080", warmup_seconds=0.0, downsample_ratio=0.5,
+                            roi_polygons=roi if i == 0 else None, motion_filter=(i == 1), motion_threshold=0.0) for i in range(2)]
+    seen = {}
+    det = HipYoloDetector(DetectorConfig(model_path="yolov8n.pt", backend="hip", half=True, confidence_threshold=0.25, warmup=False))
+    orig = det._preprocess
+    det._preprocess = lambda frames: (seen.setdefault("frames", frames), orig(frames))[1]
+    trk = IouTracker(TrackerConfig(max_age=30, max_iou_distance=0.5, min_hits=1), max_streams=2)
+    srcs = [SyntheticNv12Stream(s, index=i, n_unique=2) for i, s in enumerate(streams)]
+    pipe = TickPipeline(streams, det, trk, sources=srcs)
+    pipe.tick()
+    frames = seen["frames"]
+    assert all(isinstance(f, torch.Tensor) and tuple(f.shape) == (540, 960, 3) for f in frames)   # downsampled BGR reached the detector
+    s0 = srcs[0]._ring[0]
+    bgr = orc.nv12_to_bgr(s0.y.cpu().numpy(), s0.uv.cpu().numpy(), 1920, 1080)
+    mask = pipe._roi_masks[0].cpu().numpy()
+    want = orc.resize_linear(bgr & (mask[..., None] // 255 * 255), 960, 540)
+    assert np.array_equal(frames[0].cpu().numpy(), want)                                           # roi -> downsample order
+    assert trk.device_tracker.state()[1] == 0
