@@ -218,7 +218,8 @@ int rva_conv_cout_pad(int Cout);
 int rva_conv2d_nhwc_f16(rva_ctx *ctx, const void *in, int ldi, const void *weights, const float *bias,
                         void *out, int ldo, const void *residual, int ldr, int batch, int H, int W, int Cin,
                         int Cout, int ksize, int stride, int act, rva_stream_t stream);
-/* Same with an explicit kernel variant (0 = heuristic; 1-4 gather, 5-8 resident-chunk, 9-12 row-reuse, 13-16 gather with 64-channel K-steps): lets
+/* Same with an explicit kernel variant (0 = heuristic; 1-4 gather, 5-8 resident-chunk, 9-12 row-reuse, 13-16 gather with 64-channel K-steps,
+ * 17-20 row-reuse with two K-steps of loads in flight): lets
  * a plan time the applicable variants per layer once and keep the fastest.  RVA_ERR_ARG if not applicable. */
 int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *weights, const float *bias,
                           void *out, int ldo, const void *residual, int ldr, int batch, int H, int W, int Cin,

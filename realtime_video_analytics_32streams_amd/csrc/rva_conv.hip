@@ -49,7 +49,15 @@ struct ConvArgs {
     int H, W, Cin, CinPad, Ho, Wo, Cout, stride, M, act, n_tiles, m_tiles;   // CinPad = Cin rounded up to 32 (weight rows are zero-padded)
 };
 
-constexpr int LDSROW = 40;  // halfs per staged row: 32 data + 8 pad (80 B) -> conflict-free b128 reads
+constexpr int LDSROW = 40;  // halfs per staged row, padded layout (stem, resident kernel, K-step-64 rows use BK+8)
+
+// Swizzled layout for 32-channel (64-byte) rows, no padding: the 16-byte chunk c of row r lives at physical chunk
+// (c + 2*(r>>2)) & 3.  ds_read_b128 serves a wave in groups of 16 lanes that mix rows {0-3,12-15} at chunk c with
+// rows {4-11} at chunk c+1 (MI355X_MICROARCH.md, LDS table); with 80-byte padded rows 3 of the 16 lanes of every
+// group collide (PMC: SQ_LDS_BANK_CONFLICT = 50 % of SQ_LDS_IDX_ACTIVE on the 3x3 kernels).  For this mapping the four
+// rows of a group that share (r & 3) get physical chunks {2q, 2q+2, 2q+3, 2q+1} mod 4 -- distinct for any row base --
+// and the staging ds_write_b128 (4 lanes per row, consecutive rows) alternates 16-bank halves: both conflict-free.
+__device__ __forceinline__ int swz32(int row, int chunk) { return row * 32 + (((chunk + 2 * (row >> 2)) & 3) << 3); }
 
 // x * sigmoid(x) with v_exp_f32 + v_rcp_f32 (1 ulp): __fdividef / operator/ expand to the ~12-instruction IEEE
 // division sequence here, which dominated the epilogues (64-128 SiLUs per thread per tile)
@@ -60,7 +68,8 @@ __global__ void __launch_bounds__(256) k_conv_mfma(ConvArgs a)
 {
     constexpr int BM = 4 * WPX;
     constexpr int PARTS = BK / 8;                 // 16-byte chunks per staged row
-    constexpr int ROWH = BK + 8;                  // halfs per LDS row (16-byte pad)
+    constexpr bool SWZ = BK == 32;                // 64-byte rows: swizzled, unpadded (see swz32)
+    constexpr int ROWH = SWZ ? 32 : BK + 8;       // halfs per LDS row
     constexpr int NA = BM * PARTS / 256;          // activation chunks per thread per step
     constexpr int NW = BN * PARTS / 256;          // weight chunks per thread per step
     constexpr int TAPS = KS * KS;
@@ -131,10 +140,10 @@ __global__ void __launch_bounds__(256) k_conv_mfma(ConvArgs a)
     auto lstore = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < NA; ++i)
-            *reinterpret_cast<u4 *>(actT + ((size_t)buf * BM + tid / PARTS + RPT * i) * ROWH + part * 8) = ra[i];
+            *reinterpret_cast<u4 *>(actT + (size_t)buf * BM * ROWH + (SWZ ? swz32(tid / PARTS + RPT * i, part) : (tid / PARTS + RPT * i) * ROWH + part * 8)) = ra[i];
 #pragma unroll
         for (int i = 0; i < NW; ++i)
-            *reinterpret_cast<u4 *>(wT + ((size_t)buf * BN + tid / PARTS + RPT * i) * ROWH + part * 8) = rw[i];
+            *reinterpret_cast<u4 *>(wT + (size_t)buf * BN * ROWH + (SWZ ? swz32(tid / PARTS + RPT * i, part) : (tid / PARTS + RPT * i) * ROWH + part * 8)) = rw[i];
     };
 
     f4 acc[BN / 16][WPX / 16];
@@ -153,16 +162,17 @@ __global__ void __launch_bounds__(256) k_conv_mfma(ConvArgs a)
         if (ncc == cpt) { ncc = 0; ++ntap; }
         const bool more = s + 1 < nsteps;
         if (more) gload(ntap, ncc);                      // in flight under the MFMAs below
-        const __half *ab = actT + ((size_t)buf * BM + wv * WPX + (lane & 15)) * ROWH + (lane >> 4) * 8;
-        const __half *wb = wT + ((size_t)buf * BN + (lane & 15)) * ROWH + (lane >> 4) * 8;
+        const __half *ab0 = actT + (size_t)buf * BM * ROWH, *wb0 = wT + (size_t)buf * BN * ROWH;
+        const int arow = wv * WPX + (lane & 15), ch = lane >> 4;
 #pragma unroll
         for (int ks = 0; ks < BK / 32; ++ks) {
             h8 bf[WPX / 16];
 #pragma unroll
-            for (int j = 0; j < WPX / 16; ++j) bf[j] = *reinterpret_cast<const h8 *>(ab + j * 16 * ROWH + ks * 32);
+            for (int j = 0; j < WPX / 16; ++j)
+                bf[j] = *reinterpret_cast<const h8 *>(ab0 + (SWZ ? swz32(arow + j * 16, ch) : (arow + j * 16) * ROWH + ch * 8 + ks * 32));
 #pragma unroll
             for (int i = 0; i < BN / 16; ++i) {
-                const h8 af = *reinterpret_cast<const h8 *>(wb + i * 16 * ROWH + ks * 32);
+                const h8 af = *reinterpret_cast<const h8 *>(wb0 + (SWZ ? swz32(i * 16 + (lane & 15), ch) : (i * 16 + (lane & 15)) * ROWH + ch * 8 + ks * 32));
 #pragma unroll
                 for (int j = 0; j < WPX / 16; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[j], acc[i][j], 0, 0, 0);
             }
@@ -217,7 +227,7 @@ __global__ void __launch_bounds__(256) k_conv_mfma(ConvArgs a)
 template <int BN, int WPX, int KS, int BK>
 constexpr size_t conv_smem()
 {
-    constexpr size_t op = (size_t)2 * (4 * WPX + BN) * (BK + 8) * 2;
+    constexpr size_t op = (size_t)2 * (4 * WPX + BN) * (BK == 32 ? 32 : BK + 8) * 2;
     constexpr size_t st = (size_t)4 * WPX * (BN + 8) * 2;
     return op > st ? op : st;
 }
@@ -253,17 +263,17 @@ struct RowArgs {
     int H, W, Cin, CinPad, Cout, act, n_tiles, tiles_per_img;
 };
 
-template <int BN, int WPX>
+template <int BN, int WPX, bool PF2>
 __global__ void __launch_bounds__(256) k_conv3_row(RowArgs a)
 {
     constexpr int BM = 4 * WPX;
     constexpr int AROWS = BM + 2;
     constexpr int NA = (AROWS * 4 + 255) / 256;          // activation chunks per thread per step
     constexpr int NW = BN * 12 / 256;                      // weight chunks per thread per step (3 taps x 4 parts)
-    constexpr int WROW = 3 * LDSROW;                       // halfs per weight row: [3 dx][32 + pad]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __half *actT = (__half *)smem;                         // [2][AROWS][LDSROW]
-    __half *wT = actT + 2 * AROWS * LDSROW;                // [2][BN][3][LDSROW]
+    constexpr int AROWS_P = (AROWS + 3) & ~3;              // keep every buffer 4-row aligned for the swizzle
+    __half *actT = (__half *)smem;                         // [2][AROWS_P][32]  (swizzled 64-byte rows)
+    __half *wT = actT + 2 * AROWS_P * 32;                  // [2][3 dx][BN][32]
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int n_tile = blockIdx.x % a.n_tiles;
@@ -275,8 +285,8 @@ __global__ void __launch_bounds__(256) k_conv3_row(RowArgs a)
     const size_t wrow = (size_t)9 * a.CinPad;
     const __half *img = a.in + (size_t)b * HW * a.ldi;
 
-    u4 ra[NA], rw[NW];
-    auto gload = [&](int dy, int cc) {
+    u4 ra[NA], rw[NW], rb[NA], rx[NW];       // second set only used when PF2 (two K-steps of loads in flight)
+    auto gload_to = [&](u4 (&ra)[NA], u4 (&rw)[NW], int dy, int cc) {
         const int q0 = p0 + (dy - 1) * a.W - 1;            // raster index of tile row 0
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
@@ -292,16 +302,16 @@ __global__ void __launch_bounds__(256) k_conv3_row(RowArgs a)
             rw[i] = *reinterpret_cast<const u4 *>(a.w + (size_t)(n0 + co) * wrow + (size_t)(dy * 3 + dx) * a.CinPad + (cc << 5) + part * 8);
         }
     };
-    auto lstore = [&](int buf) {
+    auto lstore_from = [&](const u4 (&ra)[NA], const u4 (&rw)[NW], int buf) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int c = tid + 256 * i, r = c >> 2, part = c & 3;
-            if (r < AROWS) *reinterpret_cast<u4 *>(actT + ((size_t)buf * AROWS + r) * LDSROW + part * 8) = ra[i];
+            if (r < AROWS) *reinterpret_cast<u4 *>(actT + (size_t)buf * AROWS_P * 32 + swz32(r, part)) = ra[i];
         }
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
-            const int c = tid + 256 * i, part = c & 3, rowi = c >> 2;       // rowi = co*3 + dx
-            *reinterpret_cast<u4 *>(wT + ((size_t)buf * BN * 3 + rowi) * LDSROW + part * 8) = rw[i];
+            const int c = tid + 256 * i, part = c & 3, rowi = c >> 2, dxw = rowi % 3, cow = rowi / 3;
+            *reinterpret_cast<u4 *>(wT + (size_t)buf * BN * 96 + swz32(dxw * BN + cow, part)) = rw[i];
         }
     };
 
@@ -321,38 +331,60 @@ __global__ void __launch_bounds__(256) k_conv3_row(RowArgs a)
 #pragma unroll
         for (int j = 0; j < WPX / 16; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
 
-    int dy = 0, cc = 0;
-    gload(0, 0);
-    lstore(0);
-    __syncthreads();
     const h8 hz = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int s = 0; s < nsteps; ++s) {
-        const int buf = s & 1;
-        int ndy = dy, ncc = cc + 1;
-        if (ncc == cpt) { ncc = 0; ++ndy; }
-        const bool more = s + 1 < nsteps;
-        if (more) gload(ndy, ncc);
-        const __half *ab = actT + ((size_t)buf * AROWS + wv * WPX + (lane & 15)) * LDSROW + (lane >> 4) * 8;
-        const __half *wb = wT + ((size_t)buf * BN * 3 + (lane & 15) * 3) * LDSROW + (lane >> 4) * 8;
+    auto compute = [&](int buf) {
+        const __half *ab = actT + (size_t)buf * AROWS_P * 32;
+        const __half *wb = wT + (size_t)buf * BN * 96;
+        const int arow = wv * WPX + (lane & 15), ch = lane >> 4;
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
             h8 bf[WPX / 16];
 #pragma unroll
             for (int j = 0; j < WPX / 16; ++j) {
-                bf[j] = *reinterpret_cast<const h8 *>(ab + (size_t)(j * 16 + dx) * LDSROW);
+                bf[j] = *reinterpret_cast<const h8 *>(ab + swz32(arow + j * 16 + dx, ch));
                 if (dx == 0 && !okl[j]) bf[j] = hz;
                 if (dx == 2 && !okr[j]) bf[j] = hz;
             }
 #pragma unroll
             for (int i = 0; i < BN / 16; ++i) {
-                const h8 af = *reinterpret_cast<const h8 *>(wb + (size_t)(i * 48 + dx) * LDSROW);
+                const h8 af = *reinterpret_cast<const h8 *>(wb + swz32(dx * BN + i * 16 + (lane & 15), ch));
 #pragma unroll
                 for (int j = 0; j < WPX / 16; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[j], acc[i][j], 0, 0, 0);
             }
         }
-        if (more) lstore(buf ^ 1);
+    };
+    auto step_of = [&](int s, int &dy, int &cc) { dy = s / cpt; cc = s - dy * cpt; };
+    int dy, cc;
+    if (!PF2) {
+        gload_to(ra, rw, 0, 0);
+        lstore_from(ra, rw, 0);
         __syncthreads();
-        dy = ndy; cc = ncc;
+        for (int s = 0; s < nsteps; ++s) {
+            const bool more = s + 1 < nsteps;
+            if (more) { step_of(s + 1, dy, cc); gload_to(ra, rw, dy, cc); }
+            compute(s & 1);
+            if (more) lstore_from(ra, rw, (s + 1) & 1);
+            __syncthreads();
+        }
+    } else {
+        // two K-steps of global loads in flight: set A carries the even steps' successors, set B the odd ones
+        gload_to(ra, rw, 0, 0);
+        lstore_from(ra, rw, 0);
+        if (nsteps > 1) { step_of(1, dy, cc); gload_to(ra, rw, dy, cc); }      // step 1 -> set A
+        __syncthreads();
+        for (int s = 0; s < nsteps; s += 2) {
+            // even step s: prefetch s+2 into set B, compute s, store set A (= step s+1)
+            if (s + 2 < nsteps) { step_of(s + 2, dy, cc); gload_to(rb, rx, dy, cc); }
+            compute(0);
+            if (s + 1 < nsteps) lstore_from(ra, rw, 1);
+            __syncthreads();
+            if (s + 1 >= nsteps) break;
+            // odd step s+1: prefetch s+3 into set A, compute s+1, store set B (= step s+2)
+            if (s + 3 < nsteps) { step_of(s + 3, dy, cc); gload_to(ra, rw, dy, cc); }
+            compute(1);
+            if (s + 2 < nsteps) lstore_from(rb, rx, 0);
+            __syncthreads();
+        }
     }
 
     constexpr int SROW = BN + 8;
@@ -398,21 +430,21 @@ __global__ void __launch_bounds__(256) k_conv3_row(RowArgs a)
     }
 }
 
-template <int BN, int WPX>
+template <int BN, int WPX, bool PF2 = false>
 hipError_t launch_row(RowArgs &a, int batch, hipStream_t s)
 {
     constexpr int BM = 4 * WPX;
-    constexpr size_t op = (size_t)2 * ((BM + 2) + BN * 3) * LDSROW * 2;
+    constexpr size_t op = (size_t)2 * ((((BM + 2) + 3) & ~3) + BN * 3) * 32 * 2;
     constexpr size_t st = (size_t)BM * (BN + 8) * 2;
     constexpr size_t smem = op > st ? op : st;
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_conv3_row<BN, WPX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipError_t e = hipFuncSetAttribute((const void *)k_conv3_row<BN, WPX, PF2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
         attr = true;
     }
     a.tiles_per_img = rva_ceil_div(a.H * a.W, BM);
-    k_conv3_row<BN, WPX><<<batch * a.tiles_per_img * a.n_tiles, 256, smem, s>>>(a);
+    k_conv3_row<BN, WPX, PF2><<<batch * a.tiles_per_img * a.n_tiles, 256, smem, s>>>(a);
     return hipGetLastError();
 }
 
@@ -913,6 +945,7 @@ extern "C" {
 //   5..8  resident kernel <BN,WPX> = <64,64> <64,32> <128,64> <128,32>   (stride 1 only)
 //   9..12 row-reuse kernel, same tile order                               (3x3 stride 1 only)
 //   13..16 gather kernel with 64-channel K-steps, same tile order         (Cin padded to 64)
+//   17..20 row-reuse kernel with two K-steps of loads in flight           (3x3 stride 1 only)
 int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *weights, const float *bias, void *out,
                           int ldo, const void *residual, int ldr, int batch, int H, int W, int Cin, int Cout, int ksize,
                           int stride, int act, int variant, rva_stream_t stream_);
@@ -932,7 +965,7 @@ int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *wei
     if (!ctx) return RVA_ERR_ARG;
     hipStream_t s = (hipStream_t)stream_;
     if (!in || !weights || !bias || !out || batch <= 0 || H <= 0 || W <= 0 || (ksize != 1 && ksize != 3) ||
-        (stride != 1 && stride != 2) || Cin % 8 || Cout % 8 || ldi % 8 || ldo % 8 || (residual && ldr % 8) || variant < 0 || variant > 16 ||
+        (stride != 1 && stride != 2) || Cin % 8 || Cout % 8 || ldi % 8 || ldo % 8 || (residual && ldr % 8) || variant < 0 || variant > 20 ||
         ((uintptr_t)in | (uintptr_t)out | (uintptr_t)weights | (uintptr_t)residual) % 16)
         return rva_fail(ctx, RVA_ERR_ARG, "rva_conv2d_nhwc_f16: unsupported shape/alignment (Cin%%8, Cout%%8, ld%%8, 16-byte pointers)");
     ConvArgs a{};
@@ -963,6 +996,15 @@ int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *wei
 #define RVA_V(BN_, WPX_) (ksize == 1 ? launch_conv<BN_, WPX_, 1>(a, s) : launch_conv<BN_, WPX_, 3>(a, s))
             ev = v == 0 ? RVA_V(64, 64) : v == 1 ? RVA_V(64, 32) : v == 2 ? RVA_V(128, 64) : RVA_V(128, 32);
 #undef RVA_V
+        } else if (variant >= 17) {
+            if (ksize == 3 && stride == 1) {
+                RowArgs rr{};
+                rr.in = a.in; rr.ldi = ldi; rr.w = a.w; rr.bias = bias; rr.out = a.out; rr.ldo = ldo; rr.res = a.res; rr.ldr = ldr;
+                rr.H = H; rr.W = W; rr.Cin = Cin; rr.CinPad = a.CinPad; rr.Cout = Cout; rr.act = act;
+                rr.n_tiles = cpad / vbn;
+                ev = v == 0 ? launch_row<64, 64, true>(rr, batch, s) : v == 1 ? launch_row<64, 32, true>(rr, batch, s)
+                   : v == 2 ? launch_row<128, 64, true>(rr, batch, s) : launch_row<128, 32, true>(rr, batch, s);
+            }
         } else if (variant >= 13) {
             a.n_tiles = cpad / vbn;
             a.m_tiles = rva_ceil_div(a.M, 4 * vwpx);

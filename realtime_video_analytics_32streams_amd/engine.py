@@ -234,7 +234,7 @@ class FusedYoloV8:
                 state["variant"] = cache[desc][0]
                 continue
             best = (0, float("inf"))
-            for variant in range(1, 17):
+            for variant in range(1, 21):
                 if launch(stream, variant) != N.RVA_OK:
                     continue
                 torch.cuda.synchronize()

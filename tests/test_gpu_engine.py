@@ -86,7 +86,7 @@ def test_every_conv_variant_agrees(shape):
     wp, bp = wp.cuda(), bp.cuda()
     want = _conv_ref(x, w.cuda(), b.cuda(), k, stride, 1, res)
     ran = []
-    for variant in range(0, 17):
+    for variant in range(0, 21):
         out = torch.zeros_like(res)
         rc = L.rva_conv2d_nhwc_f16_v(ctx.handle, C.c_void_p(x.data_ptr()), Cin, C.c_void_p(wp.data_ptr()), C.c_void_p(bp.data_ptr()),
                                      C.c_void_p(out.data_ptr()), Cout, C.c_void_p(res.data_ptr()), Cout, B, H, W, Cin, Cout, k, stride, 1,
