@@ -215,6 +215,8 @@ int rva_tracker_set_next_id(rva_tracker *trk, int64_t next_id, rva_stream_t stre
  *   out[batch, 4+nc, anchors_total] at anchor_offset -- the `[B,84,8400]` tensor rva_postprocess_batch reads.
  * -------------------------------------------------------------------------------------------- */
 int rva_conv_cout_pad(int Cout);
+/* number of explicit kernel variants rva_conv2d_nhwc_f16_v accepts (1..N); the plan's autotuner iterates over them */
+int rva_conv_num_variants(void);
 int rva_conv2d_nhwc_f16(rva_ctx *ctx, const void *in, int ldi, const void *weights, const float *bias,
                         void *out, int ldo, const void *residual, int ldr, int batch, int H, int W, int Cin,
                         int Cout, int ksize, int stride, int act, rva_stream_t stream);

@@ -49,6 +49,20 @@ struct ConvArgs {
     int H, W, Cin, CinPad, Ho, Wo, Cout, stride, M, act, n_tiles, m_tiles;   // CinPad = Cin rounded up to 32 (weight rows are zero-padded)
 };
 
+#ifdef RVA_ROW_STAMPS
+// tuning aid (tools/row_stamps.py builds a private library with this macro): per-phase s_memtime stamps of a few blocks
+__device__ unsigned long long g_stamps[8][256];
+__device__ __forceinline__ unsigned long long stamp_now()
+{
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+#define STAMP(k) do { if (st_on && st_n < 256) g_stamps[st_slot][st_n++] = stamp_now(); } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+
 constexpr int LDSROW = 40;  // halfs per staged row, padded layout (stem, resident kernel, K-step-64 rows use BK+8)
 
 // Swizzled layout for 32-channel (64-byte) rows, no padding: the 16-byte chunk c of row r lives at physical chunk
@@ -355,16 +369,28 @@ __global__ void __launch_bounds__(256) k_conv3_row(RowArgs a)
     };
     auto step_of = [&](int s, int &dy, int &cc) { dy = s / cpt; cc = s - dy * cpt; };
     int dy, cc;
+#ifdef RVA_ROW_STAMPS
+    const int st_stride = gridDim.x / 8;
+    const bool st_on = tid == 0 && st_stride > 0 && blockIdx.x % st_stride == 0 && blockIdx.x / st_stride < 8;
+    const int st_slot = st_on ? blockIdx.x / st_stride : 0;
+    int st_n = 0;
+#endif
     if (!PF2) {
+        STAMP(0);
         gload_to(ra, rw, 0, 0);
         lstore_from(ra, rw, 0);
         __syncthreads();
+        STAMP(1);
         for (int s = 0; s < nsteps; ++s) {
             const bool more = s + 1 < nsteps;
             if (more) { step_of(s + 1, dy, cc); gload_to(ra, rw, dy, cc); }
+            STAMP(2);
             compute(s & 1);
+            STAMP(3);
             if (more) lstore_from(ra, rw, (s + 1) & 1);
+            STAMP(4);
             __syncthreads();
+            STAMP(5);
         }
     } else {
         // two K-steps of global loads in flight: set A carries the even steps' successors, set B the odd ones
@@ -428,6 +454,7 @@ __global__ void __launch_bounds__(256) k_conv3_row(RowArgs a)
             *reinterpret_cast<uint4 *>(a.out + m * a.ldo + co) = v;
         }
     }
+    STAMP(6);
 }
 
 template <int BN, int WPX, bool PF2 = false>
@@ -936,9 +963,262 @@ __global__ void __launch_bounds__(256) k_head(HeadArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// 3x3 stride-1 convolution, large-tile LDS-DMA variant ("big").
+//
+// Why: s_memtime stamps of k_conv3_row (tools/row_stamps.py) show that ~45 % of every K-step is spent ISSUING the
+// next step's global loads -- the CU's vector-memory path (64-byte row segments, ~30 GB/s per CU) is the limiter,
+// not MFMA and not LDS.  The lever is therefore MACs per staged byte: a 256 px x 128 ch tile stages 41 KB per
+// (dy, 32-channel) step for 3.1 M MACs (77 MAC/B, vs 38 for the 128 x 64 tile), at the price of one block per CU.
+// At that occupancy nothing but the block's own pipeline hides memory latency, so operands are moved by LDS-DMA
+// (global_load_lds_dwordx4: no VGPR staging, no ds_write) into a THREE-slot ring with two steps in flight, a
+// counted s_waitcnt vmcnt(N) and one raw s_barrier per step.
+//
+// Geometry: the whole batch is one flat raster of M = B*H*W pixels; a tile is BM consecutive raster pixels, so tiles
+// cross image borders and there is no per-image tail.  For vertical tap dy the inputs of the three horizontal taps
+// are the contiguous run [P0 + (dy-1)*W - 1, +BM+2); source rows are clamped into the tensor and every lane zeroes
+// the B fragments whose tap falls outside its own image (9-bit validity mask per pixel), so no zero-fill is needed
+// (LDS-DMA cannot write zeros).  LDS image: 1 KiB pieces of 16 rows x 64 B, lane-linear as LDS-DMA requires; the
+// swz32 chunk rotation is applied on the per-lane SOURCE address.  Needs Cin % 32 == 0.
+struct BigArgs {
+    const __half *in; int ldi;
+    const __half *w; const float *bias;
+    __half *out; int ldo;
+    const __half *res; int ldr;
+    int H, W, Cin, Cout, CoutPad, act, n_tiles, M;
+};
+
+typedef __attribute__((address_space(3))) void *lds_vptr;
+typedef const __attribute__((address_space(1))) void *glb_vptr;
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void wait_vm_n(int n)
+{
+    switch (n) {   // wave-uniform
+    case 0: wait_vm<0>(); break;
+    case 1: wait_vm<1>(); break;
+    case 2: wait_vm<2>(); break;
+    case 3: wait_vm<3>(); break;
+    case 4: wait_vm<4>(); break;
+    case 5: wait_vm<5>(); break;
+    case 6: wait_vm<6>(); break;
+    case 7: wait_vm<7>(); break;
+    default: wait_vm<8>(); break;
+    }
+}
+
+template <int BM, int BN, int WGM, int WGN, int NSLOT>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NSLOT == 2 ? 4 : 2))) k_conv3_big(BigArgs a)
+{
+    static_assert(WGM * WGN == 8, "eight waves");
+    static_assert(NSLOT == 2 || NSLOT == 3, "ring depth");
+    constexpr int TM = BM / WGM, TN = BN / WGN, FM = TM / 16, FN = TN / 16;
+    constexpr int APIECES = (BM + 2 + 15) / 16;           // 1 KiB pieces (16 rows x 64 B) of the activation run
+    constexpr int WPIECES = 3 * BN / 16;                  // weights [3 dx][BN] rows
+    constexpr int PIECES = APIECES + WPIECES;
+    constexpr int SLOTH = PIECES * 512;                   // halfs per ring slot
+    constexpr int NP = (PIECES + 7) / 8;                  // pieces per wave per step (upper bound)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __half *ring = (__half *)smem;                        // [NSLOT][PIECES][16][32]
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wm = wv % WGM, wn = wv / WGM;
+    const int n_tile = blockIdx.x % a.n_tiles, m_tile = blockIdx.x / a.n_tiles;
+    const int P0 = m_tile * BM, n0 = n_tile * BN;
+    const int HW = a.H * a.W;
+    const int cpt = a.Cin >> 5;
+    const int nsteps = 3 * cpt;
+    const int wrow = 9 * a.Cin;
+
+    // this wave's pieces: idx = wv + 8k.  Per-lane constants of each piece.
+    const int lrow = lane >> 2, lp = lane & 3;
+    int prow[NP];        // activation pieces: row in the run; weight pieces: element offset of the source row (tap dy=0, chunk 0)
+    int pc8[NP];         // source 16-byte chunk (swizzle inverse) * 8 halfs
+    const int my_pieces = (PIECES - wv + 7) / 8;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const int idx = wv + 8 * k;
+        if (idx < APIECES) {
+            const int r = idx * 16 + lrow;
+            prow[k] = r;
+            pc8[k] = ((lp - 2 * (r >> 2)) & 3) * 8;
+        } else {
+            const int rw = (idx - APIECES) * 16 + lrow;
+            const int dx = rw / BN, co = min(n0 + rw - dx * BN, a.CoutPad - 1);
+            prow[k] = co * wrow + dx * a.Cin;
+            pc8[k] = ((lp - 2 * (rw >> 2)) & 3) * 8;
+        }
+    }
+    // one 1 KiB LDS-DMA piece of step s (k-th piece of this wave)
+    auto issue_piece = [&](int s, int k) {
+        const int idx = wv + 8 * k;
+        if (idx < PIECES) {
+            const int dy = s / cpt, cc = s - dy * cpt;
+            __half *slot = ring + (size_t)(s % NSLOT) * SLOTH;
+            const __half *src;
+            if (idx < APIECES) {
+                const int q = min(max(P0 + (dy - 1) * a.W - 1 + prow[k], 0), a.M - 1);
+                src = a.in + (size_t)q * a.ldi + (cc << 5) + pc8[k];
+            } else {
+                src = a.w + (size_t)(prow[k] + dy * 3 * a.Cin + (cc << 5) + pc8[k]);
+            }
+            __builtin_amdgcn_global_load_lds((glb_vptr)src, (lds_vptr)(slot + idx * 512), 16, 0, 0);
+        }
+    };
+    auto issue = [&](int s) {
+#pragma unroll
+        for (int k = 0; k < NP; ++k) issue_piece(s, k);
+    };
+
+    // 9-bit tap validity per pixel fragment: bit dy*3+dx set when tap (dy,dx) of that pixel lies inside its image
+    int vm[FM];
+#pragma unroll
+    for (int j = 0; j < FM; ++j) {
+        const int p = P0 + wm * TM + 16 * j + (lane & 15);
+        int m = 0;
+        if (p < a.M) {
+            const int rem = p % HW, oy = rem / a.W, ox = rem - oy * a.W;
+            const int hv = (ox >= 1 ? 1 : 0) | 2 | (ox <= a.W - 2 ? 4 : 0);
+            m = (oy >= 1 ? hv : 0) | (hv << 3) | (oy <= a.H - 2 ? hv << 6 : 0);
+        }
+        vm[j] = m;
+    }
+
+    f4 acc[FN][FM];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+    const h8 hz = {0, 0, 0, 0, 0, 0, 0, 0};
+    // bias for the epilogue, fetched BEFORE the first LDS-DMA (so the counted vmcnt waits below never include it) and
+    // long before its use: a dependent global load at the top of the epilogue costs ~1.5 k cycles per block
+    float4 bvs[FN];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+        bvs[i] = *reinterpret_cast<const float4 *>(a.bias + min(n0 + wn * TN + 16 * i + (lane >> 4) * 4, a.CoutPad - 4));
+
+#ifdef RVA_ROW_STAMPS
+    const int st_stride = gridDim.x / 8;
+    const bool st_on = tid == 0 && st_stride > 0 && blockIdx.x % st_stride == 0 && blockIdx.x / st_stride < 8;
+    const int st_slot = st_on ? blockIdx.x / st_stride : 0;
+    int st_n = 0;
+#endif
+    STAMP(0);
+#pragma unroll
+    for (int t = 0; t < NSLOT - 1; ++t)
+        if (t < nsteps) issue(t);
+    STAMP(1);
+    for (int s = 0; s < nsteps; ++s) {
+        // retire this wave's pieces of step s (with three slots those of step s+1 stay in flight), then meet the
+        // other waves: after the barrier every piece of step s is in LDS and nobody still reads the slot that the
+        // pieces of step s+NSLOT-1 -- issued between the MFMAs below -- will overwrite
+        wait_vm_n(NSLOT == 3 && s + 1 < nsteps ? my_pieces : 0);
+        STAMP(2);
+        __builtin_amdgcn_s_barrier();
+        STAMP(3);
+        const int sn = s + NSLOT - 1;
+        const bool more = sn < nsteps;
+        if (NSLOT == 3 && more) issue(sn);        // three slots: one burst (measured faster than interleaving, profiles/r01_conv_big.txt)
+        STAMP(4);
+        const int dy = s / cpt;
+        const __half *ab = ring + (size_t)(s % NSLOT) * SLOTH;
+        const __half *wb = ab + APIECES * 512;
+        const int arow = wm * TM + (lane & 15), ch = lane >> 4;
+        const int vsh = dy * 3;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            h8 bf[FM];
+#pragma unroll
+            for (int j = 0; j < FM; ++j) {
+                bf[j] = *reinterpret_cast<const h8 *>(ab + swz32(arow + j * 16 + dx, ch));
+                if (!((vm[j] >> (vsh + dx)) & 1)) bf[j] = hz;
+            }
+#pragma unroll
+            for (int i = 0; i < FN; ++i) {
+                const h8 af = *reinterpret_cast<const h8 *>(wb + swz32(dx * BN + wn * TN + i * 16 + (lane & 15), ch));
+#pragma unroll
+                for (int j = 0; j < FM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[j], acc[i][j], 0, 0, 0);
+                // two slots (2-3 blocks per CU): one LDS-DMA piece of the next step per MFMA group
+                if (NSLOT == 2 && dx * FN + i < NP) {
+                    if (more) issue_piece(sn, dx * FN + i);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        STAMP(5);
+    }
+    __syncthreads();     // all waves done with the ring: reuse it as the output staging tile
+
+    constexpr int SROW = BN + 8;
+    __half *stage = (__half *)smem;                       // [BM][SROW]
+#pragma unroll
+    for (int i = 0; i < FN; ++i) {
+        const int co = wn * TN + 16 * i + (lane >> 4) * 4;
+        const float4 bv = bvs[i];
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+            float v0 = acc[i][j][0] + bv.x, v1 = acc[i][j][1] + bv.y, v2 = acc[i][j][2] + bv.z, v3 = acc[i][j][3] + bv.w;
+            if (a.act) { v0 = silu_f(v0); v1 = silu_f(v1); v2 = silu_f(v2); v3 = silu_f(v3); }
+            const int px = wm * TM + 16 * j + (lane & 15);
+            __half2 lo = __floats2half2_rn(v0, v1), hi = __floats2half2_rn(v2, v3);
+            uint2 pk;
+            pk.x = *reinterpret_cast<uint32_t *>(&lo);
+            pk.y = *reinterpret_cast<uint32_t *>(&hi);
+            *reinterpret_cast<uint2 *>(stage + (size_t)px * SROW + co) = pk;
+        }
+    }
+    __syncthreads();
+    constexpr int CPR = BN / 8;
+#pragma unroll 4
+    for (int q = tid; q < BM * CPR; q += 512) {
+        const int row = q / CPR, pc = q - row * CPR;
+        const int co = n0 + pc * 8;
+        const int m = P0 + row;
+        if (m < a.M && co < a.Cout) {
+            uint4 v = *reinterpret_cast<const uint4 *>(stage + (size_t)row * SROW + pc * 8);
+            if (a.res) {
+                const uint4 r = *reinterpret_cast<const uint4 *>(a.res + (size_t)m * a.ldr + co);
+                __half2 *vh = reinterpret_cast<__half2 *>(&v);
+                const __half2 *rh = reinterpret_cast<const __half2 *>(&r);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float2 x = __half22float2(vh[u]), y = __half22float2(rh[u]);
+                    vh[u] = __floats2half2_rn(x.x + y.x, x.y + y.y);
+                }
+            }
+            *reinterpret_cast<uint4 *>(a.out + (size_t)m * a.ldo + co) = v;
+        }
+    }
+    STAMP(6);
+}
+
+template <int BM, int BN, int WGM, int WGN, int NSLOT>
+hipError_t launch_big(BigArgs &a, hipStream_t s)
+{
+    constexpr size_t ring = (size_t)NSLOT * ((BM + 2 + 15) / 16 + 3 * BN / 16) * 1024;
+    constexpr size_t st = (size_t)BM * (BN + 8) * 2;
+    constexpr size_t smem = ring > st ? ring : st;
+    static_assert(smem <= 160 * 1024, "LDS budget");
+    if (a.Cin % 32 || a.CoutPad % 4) return hipErrorInvalidValue;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_conv3_big<BM, BN, WGM, WGN, NSLOT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    a.n_tiles = rva_ceil_div(a.Cout, BN);
+    k_conv3_big<BM, BN, WGM, WGN, NSLOT><<<rva_ceil_div(a.M, BM) * a.n_tiles, 512, smem, s>>>(a);
+    return hipGetLastError();
+}
+
 }  // namespace
 
+#define RVA_CONV_VARIANTS 32
+
 extern "C" {
+#ifdef RVA_ROW_STAMPS
+int rva_dbg_read_stamps(unsigned long long *host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 8 * 256); }
+#endif
 
 // variant: 0 = heuristic choice; otherwise an explicit kernel (used by the plan's per-layer autotune):
 //   1..4  gather kernel  <BN,WPX> = <64,64> <64,32> <128,64> <128,32>
@@ -946,6 +1226,9 @@ extern "C" {
 //   9..12 row-reuse kernel, same tile order                               (3x3 stride 1 only)
 //   13..16 gather kernel with 64-channel K-steps, same tile order         (Cin padded to 64)
 //   17..20 row-reuse kernel with two K-steps of loads in flight           (3x3 stride 1 only)
+//   21..24 large-tile LDS-DMA kernel <BM,BN> = <256,128> <128,128> <256,64> <128,64>, 3-slot ring (3x3 stride 1, Cin % 32 == 0)
+//   25..32 the same with a 2-slot ring, <192,128> <128,128> <256,64> <128,64> <224,128> <160,128> <384,64> <320,64>:
+//          two or three blocks per CU; the extra tile heights exist so that the tile count can fit whole rounds of the 256 CUs
 int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *weights, const float *bias, void *out,
                           int ldo, const void *residual, int ldr, int batch, int H, int W, int Cin, int Cout, int ksize,
                           int stride, int act, int variant, rva_stream_t stream_);
@@ -965,7 +1248,7 @@ int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *wei
     if (!ctx) return RVA_ERR_ARG;
     hipStream_t s = (hipStream_t)stream_;
     if (!in || !weights || !bias || !out || batch <= 0 || H <= 0 || W <= 0 || (ksize != 1 && ksize != 3) ||
-        (stride != 1 && stride != 2) || Cin % 8 || Cout % 8 || ldi % 8 || ldo % 8 || (residual && ldr % 8) || variant < 0 || variant > 20 ||
+        (stride != 1 && stride != 2) || Cin % 8 || Cout % 8 || ldi % 8 || ldo % 8 || (residual && ldr % 8) || variant < 0 || variant > RVA_CONV_VARIANTS ||
         ((uintptr_t)in | (uintptr_t)out | (uintptr_t)weights | (uintptr_t)residual) % 16)
         return rva_fail(ctx, RVA_ERR_ARG, "rva_conv2d_nhwc_f16: unsupported shape/alignment (Cin%%8, Cout%%8, ld%%8, 16-byte pointers)");
     ConvArgs a{};
@@ -984,6 +1267,32 @@ int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *wei
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess) num_cus = prop.multiProcessorCount;
         if (num_cus <= 0) num_cus = 256;
+    }
+    if (variant >= 21) {
+        // large-tile LDS-DMA kernel (3x3 stride 1, Cin % 32 == 0)
+        hipError_t ev = hipErrorInvalidValue;
+        if (ksize == 3 && stride == 1) {
+            BigArgs g{};
+            g.in = a.in; g.ldi = ldi; g.w = a.w; g.bias = bias; g.out = a.out; g.ldo = ldo; g.res = a.res; g.ldr = ldr;
+            g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.CoutPad = rva_ceil_div(Cout, 64) * 64; g.act = act; g.M = a.M;
+            switch (variant) {
+            case 21: ev = launch_big<256, 128, 4, 2, 3>(g, s); break;
+            case 22: ev = launch_big<128, 128, 2, 4, 3>(g, s); break;
+            case 23: ev = launch_big<256, 64, 4, 2, 3>(g, s); break;
+            case 24: ev = launch_big<128, 64, 2, 4, 3>(g, s); break;
+            case 25: ev = launch_big<192, 128, 4, 2, 2>(g, s); break;     // 74 KB: two blocks per CU
+            case 26: ev = launch_big<128, 128, 2, 4, 2>(g, s); break;     // 66 KB: two blocks per CU
+            case 27: ev = launch_big<256, 64, 4, 2, 2>(g, s); break;      // 58 KB: two blocks per CU
+            case 28: ev = launch_big<128, 64, 2, 4, 2>(g, s); break;      // 42 KB: three blocks per CU
+            case 29: ev = launch_big<224, 128, 2, 4, 2>(g, s); break;     // 78 KB: two blocks per CU
+            case 30: ev = launch_big<160, 128, 2, 4, 2>(g, s); break;     // 70 KB
+            case 31: ev = launch_big<384, 64, 8, 1, 2>(g, s); break;      // 74 KB
+            default: ev = launch_big<320, 64, 4, 2, 2>(g, s); break;      // 66 KB
+            }
+        }
+        if (ev == hipSuccess) return RVA_OK;
+        (void)hipGetLastError();
+        return rva_fail(ctx, ev == hipErrorInvalidValue ? RVA_ERR_ARG : RVA_ERR_HIP, "conv variant %d not applicable here", variant);
     }
     if (variant) {
         const int v = (variant - 1) & 3;                      // 0:<64,64> 1:<64,32> 2:<128,64> 3:<128,32>
@@ -1088,6 +1397,8 @@ int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *wei
 }
 
 int rva_conv_cout_pad(int Cout) { return rva_ceil_div(Cout, 64) * 64; }
+
+int rva_conv_num_variants(void) { return RVA_CONV_VARIANTS; }
 
 int rva_stem_conv_f16(rva_ctx *ctx, const void *in_planar, const void *weights, const float *bias, void *out, int ldo,
                       int batch, int H, int W, int Cout, rva_stream_t stream_)

@@ -228,13 +228,14 @@ class FusedYoloV8:
         per-chunk order of K, so the choice does not change results beyond fp32 summation order."""
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         self.tuning = []
+        self._n_variants = int(N.lib().rva_conv_num_variants())
         cache = {}
         for launch, state, desc in self._tunable:
             if desc in cache:
                 state["variant"] = cache[desc][0]
                 continue
             best = (0, float("inf"))
-            for variant in range(1, 21):
+            for variant in range(1, self._n_variants + 1):
                 if launch(stream, variant) != N.RVA_OK:
                     continue
                 torch.cuda.synchronize()

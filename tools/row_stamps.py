@@ -1,0 +1,68 @@
+"""Per-phase s_memtime stamps of the row-reuse 3x3 kernel (tuning aid).
+
+Builds a private copy of librva with -DRVA_ROW_STAMPS into tools/_dbg/ (git-ignored), runs one layer with the given
+variant and prints, for 8 sampled blocks, the cycles spent per K-step in: issue of the next step's global loads,
+LDS reads + MFMAs, wait for the loads + LDS stores, barrier.
+
+usage: python tools/row_stamps.py [--build-only] cin cout H variant
+"""
+import ctypes as C, subprocess, sys
+from pathlib import Path
+sys.path.insert(0, ".")
+from realtime_video_analytics_32streams_amd import _native as N
+
+DBG = Path("tools/_dbg/librva_stamps.so")
+
+def build():
+    DBG.parent.mkdir(exist_ok=True)
+    cmd = ["hipcc", *N.HIPCC_FLAGS, "-DRVA_ROW_STAMPS", f"-I{N.ROOT / 'include'}", "-o", str(DBG), *[str(N.CSRC / s) for s in N.SOURCES], "-ldl"]
+    subprocess.run(cmd, check=True)
+
+if not DBG.exists() or "--build-only" in sys.argv:
+    build()
+if "--build-only" in sys.argv:
+    sys.exit(0)
+
+import numpy as np, torch
+cin, cout, H, variant = [int(v) for v in sys.argv[1:5]]
+B = 32
+L = C.CDLL(str(DBG))
+ctx = C.c_void_p()
+assert L.rva_create(0, C.byref(ctx)) == 0
+s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+x = torch.randn((B, H, H, cin), device="cuda").half()
+out = torch.empty((B, H, H, cout), device="cuda", dtype=torch.float16)
+cinp = (cin + 31) // 32 * 32
+cpad = (cout + 63) // 64 * 64
+w = torch.randn((cpad, 9, cinp), device="cuda").half() * 0.05
+b = torch.zeros(cpad, device="cuda")
+L.rva_conv2d_nhwc_f16_v.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int] + [C.c_int] * 8 + [C.c_int, C.c_void_p]
+fn = lambda: L.rva_conv2d_nhwc_f16_v(ctx, x.data_ptr(), cin, w.data_ptr(), b.data_ptr(), out.data_ptr(), cout, None, 0, B, H, H, cin, cout, 3, 1, 1, variant, s)
+for _ in range(3):
+    assert fn() == 0
+torch.cuda.synchronize()
+host = np.zeros((8, 256), dtype=np.uint64)
+assert L.rva_dbg_read_stamps(host.ctypes.data_as(C.c_void_p)) == 0
+nsteps = 3 * (cinp // 32)
+for slot in range(8):
+    t = host[slot].astype(np.int64)
+    if t[0] == 0:
+        continue
+    pro = t[1] - t[0]
+    body = t[2:2 + 4 * nsteps].reshape(nsteps, 4)
+    prev = np.concatenate([[t[1]], body[:-1, 3]])
+    issue, comp, store, bar = body[:, 0] - prev, body[:, 1] - body[:, 0], body[:, 2] - body[:, 1], body[:, 3] - body[:, 2]
+    if variant >= 21:   # big kernel stamps: wait(vmcnt) | barrier | issue | compute
+        print(f"block {slot}: total {t[2 + 4 * nsteps] - t[0]}  prologue {pro}  epilogue {t[2 + 4 * nsteps] - body[-1, 3]}  per-step mean: vmcnt-wait {issue.mean():.0f} barrier {comp.mean():.0f} issue {store.mean():.0f} compute {bar.mean():.0f}  (steps {nsteps})")
+        if slot == 3:
+            for nm, arr in (("wait", issue), ("barrier", comp), ("issue", store), ("compute", bar)):
+                print(f"   steps {nm:8s}:", arr.tolist())
+        continue
+    epi = t[2 + 4 * nsteps] - body[-1, 3]
+    tot = t[2 + 4 * nsteps] - t[0]
+    print(f"block {slot}: total {tot}  prologue {pro}  epilogue {epi}  per-step mean: issue {issue.mean():.0f} compute {comp.mean():.0f} wait+store {store.mean():.0f} barrier {bar.mean():.0f}  (steps {nsteps})")
+    if slot == 3:
+        print("   steps issue  :", issue.tolist())
+        print("   steps compute:", comp.tolist())
+        print("   steps store  :", store.tolist())
+        print("   steps barrier:", bar.tolist())

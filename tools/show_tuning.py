@@ -4,16 +4,30 @@ from realtime_video_analytics_32streams_amd.engine import FusedYoloV8
 from realtime_video_analytics_32streams_amd.yolov8 import build_detector_net
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 eng = FusedYoloV8(build_detector_net(sys.argv[2] if len(sys.argv) > 2 else "s").half().cuda(), B)
-names = {0: "auto", 1: "gather<64,64>", 2: "gather<64,32>", 3: "gather<128,64>", 4: "gather<128,32>", 5: "res<64,64>", 6: "res<64,32>", 7: "res<128,64>", 8: "res<128,32>", 9: "row<64,64>", 10: "row<64,32>", 11: "row<128,64>", 12: "row<128,32>", 13: "g64<64,64>", 14: "g64<64,32>", 15: "g64<128,64>", 16: "g64<128,32>", 17: "row2<64,64>", 18: "row2<64,32>", 19: "row2<128,64>", 20: "row2<128,32>"}
+names = {0: "auto", 1: "gather<64,64>", 2: "gather<64,32>", 3: "gather<128,64>", 4: "gather<128,32>", 5: "res<64,64>", 6: "res<64,32>", 7: "res<128,64>", 8: "res<128,32>", 9: "row<64,64>", 10: "row<64,32>", 11: "row<128,64>", 12: "row<128,32>", 13: "g64<64,64>", 14: "g64<64,32>", 15: "g64<128,64>", 16: "g64<128,32>", 17: "row2<64,64>", 18: "row2<64,32>", 19: "row2<128,64>", 20: "row2<128,32>", 21: "big<256,128>", 22: "big<128,128>", 23: "big<256,64>", 24: "big<128,64>", 25: "big2<192,128>", 26: "big2<128,128>", 27: "big2<256,64>", 28: "big2<128,64>", 29: "big2<224,128>", 30: "big2<160,128>", 31: "big2<384,64>", 32: "big2<320,64>"}
 tot = 0
 seen = {}
 for launch, state, desc in eng._tunable:
     seen[desc] = seen.get(desc, 0) + 1
 t = {d: (v, us) for d, v, us in eng.tuning}
+import re
+gap_tot = 0
+rows = []
 for d, n in seen.items():
     v, us = t[d]
     tot += us * n
-    print(f"{d:28s} x{n}  {names[v]:14s} {us:8.1f} us")
+    cin, cout, k, st, h, w = map(int, re.match(r"(\d+)->(\d+) k(\d)s(\d) (\d+)x(\d+)", d).groups())
+    ho, wo = ((h - 1) // st + 1, (w - 1) // st + 1) if k == 3 else (h // st, w // st)
+    fl = 2 * B * ho * wo * cout * cin * k * k
+    by = 2 * (B * h * w * cin + B * ho * wo * cout)
+    t_hbm, t_mfma = by / 6.0e6, fl / 2.5e9          # us at 6 TB/s achievable HBM, 2.5 PFLOP/s dense fp16
+    roof = max(t_hbm, t_mfma)
+    gap = (us - roof) * n
+    gap_tot += gap
+    rows.append((gap, f"{d:24s} x{n} {names[v]:14s} {us:7.1f} us  hbm {t_hbm:6.1f}  mfma {t_mfma:6.1f}  x{us/roof:4.1f} of roof  gap*n {gap:7.1f} us"))
+for _, r in sorted(rows, reverse=True):
+    print(r)
+print("sum of gaps to the per-layer roofline:", round(gap_tot, 1), "us")
 print("sum conv us per forward:", round(tot, 1))
 x = torch.rand((B, 3, 640, 640), device="cuda").half()
 for _ in range(3): eng(x)
