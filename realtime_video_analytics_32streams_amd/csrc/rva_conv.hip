@@ -1118,33 +1118,63 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NSLOT 
         STAMP(3);
         const int sn = s + NSLOT - 1;
         const bool more = sn < nsteps;
-        if (NSLOT == 3 && more) issue(sn);        // three slots: one burst (measured faster than interleaving, profiles/r01_conv_big.txt)
+        // three slots (one block per CU, two waves per SIMD): waves w and w+4 share a SIMD, so the lower four issue
+        // their DMA burst before the MFMAs and the upper four after them -- while one wave of a SIMD is busy issuing
+        // (~750 cycles), the other one keeps the matrix core fed
+        const bool early = wv < 4;
+        if (NSLOT == 3 && more && early) issue(sn);
         STAMP(4);
         const int dy = s / cpt;
         const __half *ab = ring + (size_t)(s % NSLOT) * SLOTH;
         const __half *wb = ab + APIECES * 512;
         const int arow = wm * TM + (lane & 15), ch = lane >> 4;
         const int vsh = dy * 3;
+        // fragment registers are double-buffered across the three horizontal taps: the ds_reads of tap dx+1 are in
+        // flight under the MFMAs of tap dx (otherwise every tap exposes two LDS round trips, ~900 cycles per step)
+        constexpr int DB = NSLOT == 3 ? 1 : 0;          // the two-slot variants live within 128 VGPRs: single-buffered
+        h8 bf[DB + 1][FM], af[DB + 1][FN];
+        auto lfrag = [&](int dx, h8 (&b)[FM], h8 (&w)[FN]) {
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-            h8 bf[FM];
+            for (int j = 0; j < FM; ++j) b[j] = *reinterpret_cast<const h8 *>(ab + swz32(arow + j * 16 + dx, ch));
 #pragma unroll
-            for (int j = 0; j < FM; ++j) {
-                bf[j] = *reinterpret_cast<const h8 *>(ab + swz32(arow + j * 16 + dx, ch));
-                if (!((vm[j] >> (vsh + dx)) & 1)) bf[j] = hz;
+            for (int i = 0; i < FN; ++i) w[i] = *reinterpret_cast<const h8 *>(wb + swz32(dx * BN + wn * TN + i * 16 + (lane & 15), ch));
+        };
+        if (DB) {
+            lfrag(0, bf[0], af[0]);
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                if (dx < 2) lfrag(dx + 1, bf[(dx + 1) & DB], af[(dx + 1) & DB]);
+#pragma unroll
+                for (int j = 0; j < FM; ++j)
+                    if (!((vm[j] >> (vsh + dx)) & 1)) bf[dx & DB][j] = hz;
+#pragma unroll
+                for (int i = 0; i < FN; ++i) {
+#pragma unroll
+                    for (int j = 0; j < FM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[dx & DB][i], bf[dx & DB][j], acc[i][j], 0, 0, 0);
+                }
             }
+        } else {
 #pragma unroll
-            for (int i = 0; i < FN; ++i) {
-                const h8 af = *reinterpret_cast<const h8 *>(wb + swz32(dx * BN + wn * TN + i * 16 + (lane & 15), ch));
+            for (int dx = 0; dx < 3; ++dx) {
 #pragma unroll
-                for (int j = 0; j < FM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[j], acc[i][j], 0, 0, 0);
-                // two slots (2-3 blocks per CU): one LDS-DMA piece of the next step per MFMA group
-                if (NSLOT == 2 && dx * FN + i < NP) {
-                    if (more) issue_piece(sn, dx * FN + i);
-                    __builtin_amdgcn_sched_barrier(0);
+                for (int j = 0; j < FM; ++j) {
+                    bf[0][j] = *reinterpret_cast<const h8 *>(ab + swz32(arow + j * 16 + dx, ch));
+                    if (!((vm[j] >> (vsh + dx)) & 1)) bf[0][j] = hz;
+                }
+#pragma unroll
+                for (int i = 0; i < FN; ++i) {
+                    const h8 a1 = *reinterpret_cast<const h8 *>(wb + swz32(dx * BN + wn * TN + i * 16 + (lane & 15), ch));
+#pragma unroll
+                    for (int j = 0; j < FM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bf[0][j], acc[i][j], 0, 0, 0);
+                    // two slots (2-3 blocks per CU): one LDS-DMA piece of the next step per MFMA group
+                    if (dx * FN + i < NP) {
+                        if (more) issue_piece(sn, dx * FN + i);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
             }
         }
+        if (NSLOT == 3 && more && !early) issue(sn);
         STAMP(5);
     }
     __syncthreads();     // all waves done with the ring: reuse it as the output staging tile

@@ -28,7 +28,9 @@ cin, cout, H, variant = [int(v) for v in sys.argv[1:5]]
 B = 32
 L = C.CDLL(str(DBG))
 ctx = C.c_void_p()
+import os
 assert L.rva_create(0, C.byref(ctx)) == 0
+print('RVA_BIG_DBG =', os.environ.get('RVA_BIG_DBG'))
 s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 x = torch.randn((B, H, H, cin), device="cuda").half()
 out = torch.empty((B, H, H, cout), device="cuda", dtype=torch.float16)
