@@ -46,6 +46,7 @@ struct ConvArgs {
     const float *bias;        // [CoutPad]
     __half *out; int ldo;
     const __half *res; int ldr;
+    int CoutPad;
     int H, W, Cin, CinPad, Ho, Wo, Cout, stride, M, act, n_tiles, m_tiles;   // CinPad = Cin rounded up to 32 (weight rows are zero-padded)
 };
 
@@ -1241,9 +1242,209 @@ hipError_t launch_big(BigArgs &a, hipStream_t s)
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Large-tile LDS-DMA kernel for the gathered cases: 1x1 convolutions and 3x3 stride-2 (or stride-1) convolutions.
+// Same ring / counted-vmcnt / raw-barrier structure as k_conv3_big, but a K-step is (tap, 64 channels): every staged
+// row is one full 128-byte line of a pixel (or of a weight row), a 1 KiB piece is 8 rows, and the bank-conflict-free
+// image is the XOR swizzle  physical chunk = chunk ^ (row & 7)  (applied on the per-lane source address; for
+// ds_read_b128 fragment reads the lane's xor term is the constant lane & 7).  Every wave owns BM/64 activation pieces
+// and BN/64 weight pieces per step, so the vmcnt count is a compile-time constant.  Taps that fall outside the image
+// read a clamped address and are zeroed per lane in the B fragment (9-bit mask per pixel).  Needs Cin % 64 == 0.
+template <int BM, int BN, int WGM, int WGN, int NSLOT, int KS>
+__global__ void __launch_bounds__(512)
+    __attribute__((amdgpu_waves_per_eu(NSLOT * (BM + BN) * 128 <= 80 * 1024 ? 4 : 2))) k_conv_gbig(ConvArgs a)
+{
+    static_assert(WGM * WGN == 8, "eight waves");
+    constexpr int TM = BM / WGM, TN = BN / WGN, FM = TM / 16, FN = TN / 16;
+    constexpr int NA = BM / 64, NW = BN / 64, NPW = NA + NW;      // pieces per wave per step
+    constexpr int SLOTH = (BM + BN) * 64;                          // halfs per ring slot
+    constexpr int TAPS = KS * KS, PAD = KS / 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __half *ring = (__half *)smem;                                 // [NSLOT][BM + BN][64]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv % WGM, wn = wv / WGM;
+    const int n_tile = blockIdx.x % a.n_tiles, m_tile = blockIdx.x / a.n_tiles;
+    const int P0 = m_tile * BM, n0 = n_tile * BN;
+    const int HoWo = a.Ho * a.Wo;
+    const int cpt = a.Cin >> 6;
+    const int nsteps = TAPS * cpt;
+    const int wrow = TAPS * a.Cin;
+
+    // per-lane constants of this wave's pieces (piece index = wv + 8k: k < NA activations, then weights)
+    const int lrow = lane >> 3, c8 = ((lane & 7) ^ lrow) * 8;      // source chunk of this lane (swizzle inverse)
+    int apix[NA], ayx[NA];      // flat input pixel of tap (0,0) and packed (iy0 + 2048) << 16 | (ix0 + 2048)
+#pragma unroll
+    for (int k = 0; k < NA; ++k) {
+        const int m = P0 + (wv + 8 * k) * 8 + lrow;
+        if (m < a.M) {
+            const int b = m / HoWo, rem = m - b * HoWo, oy = rem / a.Wo, ox = rem - oy * a.Wo;
+            const int iy0 = oy * a.stride - PAD, ix0 = ox * a.stride - PAD;
+            apix[k] = (b * a.H + iy0) * a.W + ix0;
+            ayx[k] = ((iy0 + 2048) << 16) | (ix0 + 2048);
+        } else {
+            apix[k] = 0;
+            ayx[k] = 0;                                            // iy0 = ix0 = -2048: never valid
+        }
+    }
+    int woff[NW];
+#pragma unroll
+    for (int k = 0; k < NW; ++k) woff[k] = min(n0 + (wv + 8 * k) * 8 + lrow, a.CoutPad - 1) * wrow + c8;
+
+    auto issue = [&](int s) {
+        const int tap = s / cpt, cc = s - tap * cpt;
+        const int dy = KS == 1 ? 0 : tap / 3, dx = KS == 1 ? 0 : tap - dy * 3;
+        __half *slot = ring + (size_t)(s % NSLOT) * SLOTH;
+#pragma unroll
+        for (int k = 0; k < NA; ++k) {
+            const int iy = (ayx[k] >> 16) - 2048 + dy, ix = (ayx[k] & 0xffff) - 2048 + dx;
+            const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const int q = ok ? apix[k] + dy * a.W + dx : 0;
+            const __half *src = a.in + (size_t)q * a.ldi + (cc << 6) + c8;
+            __builtin_amdgcn_global_load_lds((glb_vptr)src, (lds_vptr)(slot + (wv + 8 * k) * 512), 16, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            const __half *src = a.w + (size_t)(woff[k] + tap * a.Cin + (cc << 6));
+            __builtin_amdgcn_global_load_lds((glb_vptr)src, (lds_vptr)(slot + BM * 64 + (wv + 8 * k) * 512), 16, 0, 0);
+        }
+    };
+
+    // tap validity of this lane's pixels (bit = tap index); 1x1: every tap valid
+    int vm[FM];
+#pragma unroll
+    for (int j = 0; j < FM; ++j) {
+        int msk = KS == 1 ? 1 : 0;
+        if (KS == 3) {
+            const int m = P0 + wm * TM + 16 * j + (lane & 15);
+            if (m < a.M) {
+                const int b = m / HoWo, rem = m - b * HoWo, oy = rem / a.Wo, ox = rem - oy * a.Wo;
+                const int iy0 = oy * a.stride - 1, ix0 = ox * a.stride - 1;
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+                    if ((unsigned)(iy0 + t / 3) < (unsigned)a.H && (unsigned)(ix0 + t % 3) < (unsigned)a.W) msk |= 1 << t;
+            }
+        }
+        vm[j] = msk;
+    }
+
+    f4 acc[FN][FM];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+    const h8 hz = {0, 0, 0, 0, 0, 0, 0, 0};
+    float4 bvs[FN];                                                // before the first DMA: see k_conv3_big
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+        bvs[i] = *reinterpret_cast<const float4 *>(a.bias + min(n0 + wn * TN + 16 * i + (lane >> 4) * 4, a.CoutPad - 4));
+
+#pragma unroll
+    for (int t = 0; t < NSLOT - 1; ++t)
+        if (t < nsteps) issue(t);
+    const int xr = lane & 7;                                       // (row & 7) of every fragment row this lane reads
+    for (int s = 0; s < nsteps; ++s) {
+        if (NSLOT == 3 && s + 1 < nsteps) wait_vm<NPW>(); else wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        const int sn = s + NSLOT - 1;
+        const bool more = sn < nsteps;
+        const bool early = NSLOT == 2 || wv < 4;
+        if (more && early) issue(sn);
+        const int tap = s / cpt;
+        const __half *ab = ring + (size_t)(s % NSLOT) * SLOTH;
+        const __half *wb = ab + BM * 64;
+        const int arow = wm * TM + (lane & 15), wr = wn * TN + (lane & 15);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int pc = ((ks * 4 + (lane >> 4)) ^ xr) * 8;
+            h8 bf[FM];
+#pragma unroll
+            for (int j = 0; j < FM; ++j) {
+                bf[j] = *reinterpret_cast<const h8 *>(ab + (arow + 16 * j) * 64 + pc);
+                if (KS == 3 && !((vm[j] >> tap) & 1)) bf[j] = hz;
+            }
+#pragma unroll
+            for (int i = 0; i < FN; ++i) {
+                const h8 af = *reinterpret_cast<const h8 *>(wb + (wr + 16 * i) * 64 + pc);
+#pragma unroll
+                for (int j = 0; j < FM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (more && !early) issue(sn);
+    }
+    __syncthreads();     // ring drained and no longer read: reuse it as the output staging tile
+
+    constexpr int SROW = BN + 8;
+    __half *stage = (__half *)smem;                                // [BM][SROW]
+#pragma unroll
+    for (int i = 0; i < FN; ++i) {
+        const int co = wn * TN + 16 * i + (lane >> 4) * 4;
+        const float4 bv = bvs[i];
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+            float v0 = acc[i][j][0] + bv.x, v1 = acc[i][j][1] + bv.y, v2 = acc[i][j][2] + bv.z, v3 = acc[i][j][3] + bv.w;
+            if (a.act) { v0 = silu_f(v0); v1 = silu_f(v1); v2 = silu_f(v2); v3 = silu_f(v3); }
+            const int px = wm * TM + 16 * j + (lane & 15);
+            __half2 lo = __floats2half2_rn(v0, v1), hi = __floats2half2_rn(v2, v3);
+            uint2 pk;
+            pk.x = *reinterpret_cast<uint32_t *>(&lo);
+            pk.y = *reinterpret_cast<uint32_t *>(&hi);
+            *reinterpret_cast<uint2 *>(stage + (size_t)px * SROW + co) = pk;
+        }
+    }
+    __syncthreads();
+    constexpr int CPR = BN / 8;
+#pragma unroll 4
+    for (int q = tid; q < BM * CPR; q += 512) {
+        const int row = q / CPR, pc = q - row * CPR;
+        const int co = n0 + pc * 8;
+        const int m = P0 + row;
+        if (m < a.M && co < a.Cout) {
+            uint4 v = *reinterpret_cast<const uint4 *>(stage + (size_t)row * SROW + pc * 8);
+            if (a.res) {
+                const uint4 r = *reinterpret_cast<const uint4 *>(a.res + (size_t)m * a.ldr + co);
+                __half2 *vh = reinterpret_cast<__half2 *>(&v);
+                const __half2 *rh = reinterpret_cast<const __half2 *>(&r);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float2 x = __half22float2(vh[u]), y = __half22float2(rh[u]);
+                    vh[u] = __floats2half2_rn(x.x + y.x, x.y + y.y);
+                }
+            }
+            *reinterpret_cast<uint4 *>(a.out + (size_t)m * a.ldo + co) = v;
+        }
+    }
+}
+
+template <int BM, int BN, int WGM, int WGN, int NSLOT, int KS>
+hipError_t launch_gbig1(ConvArgs &a, hipStream_t s)
+{
+    constexpr size_t ring = (size_t)NSLOT * (BM + BN) * 128;
+    constexpr size_t st = (size_t)BM * (BN + 8) * 2;
+    constexpr size_t smem = ring > st ? ring : st;
+    static_assert(smem <= 160 * 1024, "LDS budget");
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_conv_gbig<BM, BN, WGM, WGN, NSLOT, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    a.n_tiles = rva_ceil_div(a.Cout, BN);
+    k_conv_gbig<BM, BN, WGM, WGN, NSLOT, KS><<<rva_ceil_div(a.M, BM) * a.n_tiles, 512, smem, s>>>(a);
+    return hipGetLastError();
+}
+
+template <int BM, int BN, int WGM, int WGN, int NSLOT>
+hipError_t launch_gbig(ConvArgs &a, int ksize, hipStream_t s)
+{
+    if (a.Cin % 64 || a.H > 2000 || a.W > 2000) return hipErrorInvalidValue;
+    return ksize == 1 ? launch_gbig1<BM, BN, WGM, WGN, NSLOT, 1>(a, s) : launch_gbig1<BM, BN, WGM, WGN, NSLOT, 3>(a, s);
+}
+
 }  // namespace
 
-#define RVA_CONV_VARIANTS 32
+#define RVA_CONV_VARIANTS 39
 
 extern "C" {
 #ifdef RVA_ROW_STAMPS
@@ -1259,6 +1460,8 @@ int rva_dbg_read_stamps(unsigned long long *host) { return (int)hipMemcpyFromSym
 //   21..24 large-tile LDS-DMA kernel <BM,BN> = <256,128> <128,128> <256,64> <128,64>, 3-slot ring (3x3 stride 1, Cin % 32 == 0)
 //   25..32 the same with a 2-slot ring, <192,128> <128,128> <256,64> <128,64> <224,128> <160,128> <384,64> <320,64>:
 //          two or three blocks per CU; the extra tile heights exist so that the tile count can fit whole rounds of the 256 CUs
+//   33..38 large-tile LDS-DMA gather kernel with 64-channel K-steps (1x1; 3x3 stride 1 or 2; Cin % 64 == 0):
+//          <256,128> <128,128> <256,64> <128,64> 3-slot, <128,128> <256,64> <192,128> 2-slot
 int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *weights, const float *bias, void *out,
                           int ldo, const void *residual, int ldr, int batch, int H, int W, int Cin, int Cout, int ksize,
                           int stride, int act, int variant, rva_stream_t stream_);
@@ -1297,6 +1500,24 @@ int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *wei
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess) num_cus = prop.multiProcessorCount;
         if (num_cus <= 0) num_cus = 256;
+    }
+    if (variant >= 33) {
+        // large-tile LDS-DMA gather kernel, 64-channel K-steps (1x1, and 3x3 of either stride; Cin % 64 == 0)
+        a.CoutPad = cpad;
+        if (ksize == 1 && stride != 1) return rva_fail(ctx, RVA_ERR_ARG, "conv variant %d not applicable here", variant);
+        hipError_t ev;
+        switch (variant) {
+        case 33: ev = launch_gbig<256, 128, 4, 2, 3>(a, ksize, s); break;    // 144 KB, one block per CU
+        case 34: ev = launch_gbig<128, 128, 2, 4, 3>(a, ksize, s); break;    // 96 KB
+        case 35: ev = launch_gbig<256, 64, 4, 2, 3>(a, ksize, s); break;     // 120 KB
+        case 36: ev = launch_gbig<128, 64, 2, 4, 3>(a, ksize, s); break;     // 72 KB: two blocks per CU
+        case 37: ev = launch_gbig<128, 128, 2, 4, 2>(a, ksize, s); break;    // 64 KB: two blocks per CU
+        case 38: ev = launch_gbig<256, 64, 4, 2, 2>(a, ksize, s); break;     // 80 KB: two blocks per CU
+        default: ev = launch_gbig<192, 128, 4, 2, 2>(a, ksize, s); break;    // 80 KB: two blocks per CU
+        }
+        if (ev == hipSuccess) return RVA_OK;
+        (void)hipGetLastError();
+        return rva_fail(ctx, ev == hipErrorInvalidValue ? RVA_ERR_ARG : RVA_ERR_HIP, "conv variant %d not applicable here", variant);
     }
     if (variant >= 21) {
         // large-tile LDS-DMA kernel (3x3 stride 1, Cin % 32 == 0)
