@@ -1501,6 +1501,20 @@ int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *wei
         if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess) num_cus = prop.multiProcessorCount;
         if (num_cus <= 0) num_cus = 256;
     }
+    if (variant == 0) {
+        // heuristic (callers that do not autotune): the LDS-DMA kernels wherever their channel constraints hold,
+        // tile picked from the autotune tables of the YOLOv8 layers (tools/show_tuning.py)
+        int pick = 0;
+        if (ksize == 3 && stride == 1 && Cin % 32 == 0)
+            pick = cpad % 128 == 0 ? ((long)a.M * Cout >= 20000000L ? 25 : 21) : (a.M >= 100000 ? 31 : 23);
+        else if (Cin % 64 == 0 && (ksize == 3 || stride == 1))
+            pick = 37;
+        if (pick) {
+            const int rc = rva_conv2d_nhwc_f16_v(ctx, in, ldi, weights, bias, out, ldo, residual, ldr, batch, H, W, Cin, Cout, ksize,
+                                                 stride, act, pick, stream_);
+            if (rc == RVA_OK) return rc;
+        }
+    }
     if (variant >= 33) {
         // large-tile LDS-DMA gather kernel, 64-channel K-steps (1x1, and 3x3 of either stride; Cin % 64 == 0)
         a.CoutPad = cpad;

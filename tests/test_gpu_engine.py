@@ -70,7 +70,11 @@ def test_conv_primitive_matches_fp32_reference(shape):
 
 
 @pytest.mark.parametrize("shape", [(2, 20, 20, 64, 64, 3, 1), (3, 17, 23, 96, 128, 3, 1), (1, 40, 40, 128, 128, 3, 1), (2, 9, 7, 32, 64, 3, 1),
-                                   (2, 20, 20, 128, 128, 1, 1), (2, 20, 20, 64, 128, 3, 2)])
+                                   (2, 20, 20, 128, 128, 1, 1), (2, 20, 20, 64, 128, 3, 2),
+                                   # LDS-DMA kernels: odd sizes with stride 2, Cout that is no multiple of the channel tile,
+                                   # a tensor smaller than one tile, tiles that straddle image borders, many tiles
+                                   (3, 17, 23, 64, 80, 3, 2), (2, 13, 11, 128, 80, 1, 1), (1, 5, 5, 64, 64, 3, 1),
+                                   (5, 12, 10, 64, 192, 3, 1), (4, 80, 80, 64, 64, 3, 1), (2, 40, 40, 192, 128, 1, 1)])
 def test_every_conv_variant_agrees(shape):
     """All kernel variants the autotuner may pick (gather / resident / row-reuse, every tile) give the same layer."""
     B, H, W, Cin, Cout, k, stride = shape
