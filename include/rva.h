@@ -35,7 +35,7 @@ enum rva_status {
     RVA_ERR_UNAVAILABLE = 4  /* optional component (rocDecode) not present on this machine */
 };
 
-enum rva_dtype { RVA_F16 = 0, RVA_F32 = 1 };
+enum rva_dtype { RVA_F16 = 0, RVA_F32 = 1, RVA_F64 = 2 /* only where an entry point says so */ };
 
 typedef struct rva_ctx rva_ctx;
 typedef struct rva_tracker rva_tracker;
@@ -96,6 +96,27 @@ int rva_preprocess_clip_nv12_batch(rva_ctx *ctx, const void *const *y_ptrs, cons
 int rva_preprocess_clip_bgr_batch(rva_ctx *ctx, const void *const *frames, const int32_t *row_bytes,
                                   int n, int src_w, int src_h, void *out, int out_dtype, int dst_w,
                                   int dst_h, rva_stream_t stream);
+
+/* Frame pre-process of the remaining classification / temporal heads: stretch-resize to
+ * (dst_w, dst_h) with cv2.resize defaults, BGR2RGB, image.astype(float32) / 255.0, (image - mean) / std, CHW.
+ *   norm RVA_NORM_IMAGENET_F32: float32 ImageNet constants -- CNNLSTMDetector (temporal_detector.py:350-354) and the
+ *        ResNet classifiers' _preprocess (detector.py:980-1001);
+ *   norm RVA_NORM_VIDEO_F32:    float32 mean 0.45 / std 0.225 on every channel -- CNN3DDetector (:570-573);
+ *   norm RVA_NORM_IMAGENET_F64: ImageNet constants held in float64 arrays, so the float32 image is promoted and the
+ *        subtraction / division run in float64 -- ConvGRUDetector (:741-743).  The reference then hands over float64
+ *        (out_dtype RVA_F64) or casts float64 -> float16 in one rounding (RVA_F16); RVA_F32 is that value rounded once.
+ *   layout RVA_LAYOUT_NCHW: out[n][3][H][W] (frames stacked on axis 0: CNN-LSTM / ConvGRU clips [T,C,H,W], ResNet);
+ *   layout RVA_LAYOUT_CNHW: out[3][n][H][W] (3D-CNN clips [C,T,H,W], temporal_detector.py:583-590).
+ * RVA_F64 is accepted with RVA_NORM_IMAGENET_F64 only.  rva_preprocess_clip_* = (IMAGENET_F32, NCHW). */
+enum rva_frame_norm { RVA_NORM_IMAGENET_F32 = 0, RVA_NORM_VIDEO_F32 = 1, RVA_NORM_IMAGENET_F64 = 2 };
+enum rva_frame_layout { RVA_LAYOUT_NCHW = 0, RVA_LAYOUT_CNHW = 1 };
+int rva_preprocess_frames_nv12_batch(rva_ctx *ctx, const void *const *y_ptrs, const void *const *uv_ptrs,
+                                     const int32_t *pitches, int n, int src_w, int src_h, void *out,
+                                     int out_dtype, int dst_w, int dst_h, int norm, int layout,
+                                     rva_stream_t stream);
+int rva_preprocess_frames_bgr_batch(rva_ctx *ctx, const void *const *frames, const int32_t *row_bytes,
+                                    int n, int src_w, int src_h, void *out, int out_dtype, int dst_w,
+                                    int dst_h, int norm, int layout, rva_stream_t stream);
 
 /* ----------------------------------------------------------------------------------------------
  * K2+K3 post-process -- replaces _TensorRTBaseDetector._postprocess with _xywh2xyxy, _scale_boxes,

@@ -173,6 +173,42 @@ def preprocess_clip_frame(bgr=None, nv12=None, wh=None, tw=224, th=224, half=Fal
     return out
 
 
+_NORM_DT = {0: np.float16, 1: np.float32, 2: np.float64}
+
+
+def preprocess_norm_frames(frames, tw, th, norm, out_dtype, layout=0, nv12_wh=None):
+    """SURVEY 8f-4 pre-process of a list of frames (BGR uint8 arrays, or (y, uv) NV12 pairs with ``nv12_wh``):
+    returns ``[n,3,th,tw]`` (layout 0) or ``[3,n,th,tw]`` (layout 1) in float16/32/64 (``out_dtype`` 0/1/2)."""
+    n = len(frames)
+    shape = (n, 3, th, tw) if layout == 0 else (3, n, th, tw)
+    out = np.empty(shape, _NORM_DT[out_dtype])
+    plane = th * tw
+    fstride, cstride = (3 * plane, plane) if layout == 0 else (plane, n * plane)
+    base = out.ctypes.data
+    for i, f in enumerate(frames):
+        dst = C.c_void_p(base + i * fstride * out.itemsize)
+        if nv12_wh is None:
+            bgr = np.ascontiguousarray(f, np.uint8)
+            h, w = bgr.shape[:2]
+            lib().orc_preprocess_norm_frame_bgr(C.c_void_p(bgr.ctypes.data), w, h, tw, th, norm, out_dtype, dst,
+                                                C.c_long(cstride))
+        else:
+            y, uv = np.ascontiguousarray(f[0]), np.ascontiguousarray(f[1])
+            w, h = nv12_wh
+            lib().orc_preprocess_norm_frame_nv12(C.c_void_p(y.ctypes.data), C.c_void_p(uv.ctypes.data),
+                                                 C.c_int(y.shape[1]), w, h, tw, th, norm, out_dtype, dst, C.c_long(cstride))
+    return out
+
+
+def resize_bgr(bgr, tw, th):
+    """cv2.resize(bgr, (tw, th)) restated (INTER_LINEAR 11-bit fixed point): the uint8 image the normalisers see."""
+    bgr = np.ascontiguousarray(bgr, np.uint8)
+    h, w = bgr.shape[:2]
+    out = np.empty((th, tw, 3), np.uint8)
+    lib().orc_resize_linear_u8c3(C.c_void_p(bgr.ctypes.data), w, h, C.c_void_p(out.ctypes.data), tw, th)
+    return out
+
+
 def clip_schedule(L, stride, overlap, n_frames):
     cap = n_frames
     fired = np.empty(cap, np.int32); ids = np.empty((cap, L), np.int32)

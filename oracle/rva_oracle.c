@@ -466,6 +466,51 @@ ORC_API void orc_preprocess_clip_frame_bgr(const uint8_t *bgr, int w, int h, int
     free(rs);
 }
 
+/*
+ * The same frame body with the constants / precision of the other heads:
+ *   norm 0: float32 ImageNet constants  -- temporal_detector.py:350-354 (CNN-LSTM), detector.py:988-993 (ResNet)
+ *   norm 1: float32 0.45 / 0.225        -- temporal_detector.py:570-573 (3D-CNN)
+ *   norm 2: float64 ImageNet constants  -- temporal_detector.py:741-743 (ConvGRU: np.array([...]) without dtype, so
+ *           the float32 image is promoted and (image - mean) / std runs in float64)
+ * out_dtype 0 = float16 (cast of the float32 / float64 result, one rounding), 1 = float32, 2 = float64.
+ * Channel c is written at out + c * cstride (elements): cstride = th*tw for [C,H,W], T*th*tw inside a [C,T,H,W] clip.
+ */
+ORC_API void orc_preprocess_norm_frame_bgr(const uint8_t *bgr, int w, int h, int tw, int th, int norm, int out_dtype,
+                                           void *out, long cstride)
+{
+    static const float meanf[3] = {0.485f, 0.456f, 0.406f}, stdf[3] = {0.229f, 0.224f, 0.225f};
+    static const double meand[3] = {0.485, 0.456, 0.406}, stdd[3] = {0.229, 0.224, 0.225};
+    uint8_t *rs = (uint8_t *)malloc((size_t)tw * th * 3);
+    orc_resize_linear_u8c3(bgr, w, h, rs, tw, th);
+    size_t plane = (size_t)tw * th;
+    for (int c = 0; c < 3; ++c)
+        for (size_t i = 0; i < plane; ++i) {
+            float x = (float)rs[i * 3 + (2 - c)] / 255.0f;
+            double d;
+            if (norm == 2) {
+                d = ((double)x - meand[c]) / stdd[c];
+            } else {
+                float m = norm == 1 ? 0.45f : meanf[c], sd = norm == 1 ? 0.225f : stdf[c];
+                float r = (x - m) / sd;
+                d = (double)r;
+            }
+            size_t o = (size_t)c * (size_t)cstride + i;
+            if (out_dtype == 0) ((uint16_t *)out)[o] = f64_to_f16(d);
+            else if (out_dtype == 1) ((float *)out)[o] = (float)d;
+            else ((double *)out)[o] = d;
+        }
+    free(rs);
+}
+
+ORC_API void orc_preprocess_norm_frame_nv12(const uint8_t *y, const uint8_t *uv, int pitch, int w, int h, int tw, int th,
+                                            int norm, int out_dtype, void *out, long cstride)
+{
+    uint8_t *bgr = (uint8_t *)malloc((size_t)w * h * 3);
+    orc_nv12_to_bgr(y, uv, pitch, w, h, bgr);
+    orc_preprocess_norm_frame_bgr(bgr, w, h, tw, th, norm, out_dtype, out, cstride);
+    free(bgr);
+}
+
 ORC_API void orc_preprocess_clip_frame_nv12(const uint8_t *y, const uint8_t *uv, int pitch, int w, int h,
                                             int tw, int th, int half, void *out)
 {

@@ -24,7 +24,9 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17",
                "-Wall", "-Wno-unused-function"]
 
 RVA_OK, RVA_ERR_ARG, RVA_ERR_HIP, RVA_ERR_CAPACITY, RVA_ERR_UNAVAILABLE = range(5)
-RVA_F16, RVA_F32 = 0, 1
+RVA_F16, RVA_F32, RVA_F64 = 0, 1, 2
+NORM_IMAGENET_F32, NORM_VIDEO_F32, NORM_IMAGENET_F64 = 0, 1, 2      # enum rva_frame_norm
+LAYOUT_NCHW, LAYOUT_CNHW = 0, 1                                    # enum rva_frame_layout
 RVA_MAX_BATCH = 64
 
 
@@ -96,6 +98,10 @@ def lib() -> C.CDLL:
                                                      C.c_int, _P]),
         "rva_preprocess_clip_bgr_batch": (C.c_int, [_P, pp, i32p, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int,
                                                     C.c_int, _P]),
+        "rva_preprocess_frames_nv12_batch": (C.c_int, [_P, pp, pp, i32p, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int,
+                                                       C.c_int, C.c_int, C.c_int, _P]),
+        "rva_preprocess_frames_bgr_batch": (C.c_int, [_P, pp, i32p, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int,
+                                                      C.c_int, C.c_int, C.c_int, _P]),
         "rva_postprocess_batch": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, i32p,
                                             C.c_int, C.POINTER(Letterbox), C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P,
                                             _P]),
@@ -143,7 +149,7 @@ def lib() -> C.CDLL:
 EXPORTS = [
     "rva_abi_version", "rva_create", "rva_destroy", "rva_last_error", "rva_reserve", "rva_letterbox_meta",
     "rva_preprocess_nv12_batch", "rva_preprocess_bgr_batch", "rva_preprocess_clip_nv12_batch",
-    "rva_preprocess_clip_bgr_batch", "rva_postprocess_batch", "rva_post_status", "rva_tracker_create",
+    "rva_preprocess_clip_bgr_batch", "rva_preprocess_frames_nv12_batch", "rva_preprocess_frames_bgr_batch", "rva_postprocess_batch", "rva_post_status", "rva_tracker_create",
     "rva_tracker_destroy", "rva_tracker_update_f32", "rva_tracker_update_f64", "rva_tracker_new_counts",
     "rva_tracker_assign_ids", "rva_tracker_read", "rva_tracker_read_all", "rva_tracker_snapshot_async",
     "rva_tracker_snapshot_fetch", "rva_tracker_state",

@@ -35,6 +35,8 @@ struct K1Args {
     const int32_t *xofs; const int16_t *xw0, *xw1;
     const int32_t *yofs; const int16_t *yw0, *yw1;
     void *out;
+    int norm;                          // MODE 1: rva_frame_norm
+    long fstride, cstride;             // MODE 1: output element strides between frames / channels
 };
 
 __device__ __forceinline__ int clip8(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
@@ -59,15 +61,35 @@ template <> struct Vec8<float> { float4 lo, hi; };
 __device__ __forceinline__ __half norm_yolo(int v, __half) { return __hmul(__int2half_rn(v), __ushort_as_half(kInv255Half)); }
 __device__ __forceinline__ float norm_yolo(int v, float) { return (float)v * (float)(1.0 / 255.0); }
 
-// temporal_detector.py:350-354: float32 /255.0 then (x-mean)/std, cast last (:368-371)
-__device__ __forceinline__ float norm_clip32(int v, int c)
-{
-    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
-    float x = __fdiv_rn((float)v, 255.0f);
-    return __fdiv_rn(x - mean[c], stdv[c]);
+// temporal_detector.py:350-354 / :570-573 / :741-743, detector.py:988-993: float32 /255.0, then (x-mean)/std in
+// float32 (norm 0, 1) or -- ConvGRU's float64 constant arrays -- in float64 (norm 2); the dtype cast comes last
+__device__ __forceinline__ __half d2h_rn(double d)
+{   // one rounding double -> half: truncate to float keeping a sticky bit (round to odd), then round to nearest
+    float f = __double2float_rz(d);
+    if ((double)f != d) f = __uint_as_float(__float_as_uint(f) | 1u);
+    return __float2half_rn(f);
 }
-__device__ __forceinline__ __half norm_clip(int v, int c, __half) { return __float2half_rn(norm_clip32(v, c)); }
-__device__ __forceinline__ float norm_clip(int v, int c, float) { return norm_clip32(v, c); }
+__device__ __forceinline__ void cast_out(double d, __half &o) { o = d2h_rn(d); }
+__device__ __forceinline__ void cast_out(double d, float &o) { o = (float)d; }
+__device__ __forceinline__ void cast_out(double d, double &o) { o = d; }
+__device__ __forceinline__ void cast_out(float f, __half &o) { o = __float2half_rn(f); }
+__device__ __forceinline__ void cast_out(float f, float &o) { o = f; }
+__device__ __forceinline__ void cast_out(float f, double &o) { o = (double)f; }
+template <typename OutT>
+__device__ __forceinline__ OutT norm_frame(int v, int c, int norm)
+{
+    const float x = __fdiv_rn((float)v, 255.0f);
+    OutT o;
+    if (norm == 2) {
+        const double mean[3] = {0.485, 0.456, 0.406}, stdv[3] = {0.229, 0.224, 0.225};
+        cast_out(((double)x - mean[c]) / stdv[c], o);
+    } else {
+        const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+        const float m = norm == 1 ? 0.45f : mean[c], sd = norm == 1 ? 0.225f : stdv[c];
+        cast_out(__fdiv_rn(x - m, sd), o);
+    }
+    return o;
+}
 
 template <typename OutT>
 __device__ __forceinline__ void store8(OutT *dst, const OutT *v, bool vec_ok, int nvalid)
@@ -75,9 +97,12 @@ __device__ __forceinline__ void store8(OutT *dst, const OutT *v, bool vec_ok, in
     if (vec_ok && nvalid == 8) {
         if constexpr (sizeof(OutT) == 2) {
             *reinterpret_cast<uint4 *>(dst) = *reinterpret_cast<const uint4 *>(v);
-        } else {
+        } else if constexpr (sizeof(OutT) == 4) {
             reinterpret_cast<float4 *>(dst)[0] = reinterpret_cast<const float4 *>(v)[0];
             reinterpret_cast<float4 *>(dst)[1] = reinterpret_cast<const float4 *>(v)[1];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) reinterpret_cast<double2 *>(dst)[i] = reinterpret_cast<const double2 *>(v)[i];
         }
     } else {
         for (int i = 0; i < nvalid; ++i) dst[i] = v[i];
@@ -190,7 +215,8 @@ __global__ void __launch_bounds__(256) k1_generic(K1Args a)
     const int ox = xg << 3;
     const int nvalid = a.dst_w - ox < 8 ? a.dst_w - ox : 8;
     const size_t plane = (size_t)a.dst_w * a.dst_h;
-    OutT *out = (OutT *)a.out + (size_t)img * 3 * plane + (size_t)oy * a.dst_w + ox;
+    const size_t fstride = MODE == 1 ? (size_t)a.fstride : 3 * plane, cstride = MODE == 1 ? (size_t)a.cstride : plane;
+    OutT *out = (OutT *)a.out + (size_t)img * fstride + (size_t)oy * a.dst_w + ox;
     alignas(16) OutT vr[8], vg[8], vb[8];
     const uint8_t *p0 = a.p0[img];
     const uint8_t *p1 = a.p1[img];
@@ -244,16 +270,16 @@ __global__ void __launch_bounds__(256) k1_generic(K1Args a)
                 o8[0] = (uint8_t)b; o8[1] = (uint8_t)g; o8[2] = (uint8_t)r;
             }
         } else if constexpr (MODE == 1) {
-            vr[i] = norm_clip(r, 0, OutT()); vg[i] = norm_clip(g, 1, OutT()); vb[i] = norm_clip(b, 2, OutT());
-        } else {
+            vr[i] = norm_frame<OutT>(r, 0, a.norm); vg[i] = norm_frame<OutT>(g, 1, a.norm); vb[i] = norm_frame<OutT>(b, 2, a.norm);
+        } else if constexpr (sizeof(OutT) <= 4) {
             vr[i] = norm_yolo(r, OutT()); vg[i] = norm_yolo(g, OutT()); vb[i] = norm_yolo(b, OutT());
         }
     }
     if constexpr (MODE == 2) return;
     const bool vec_ok = (a.dst_w & 7) == 0;
     store8<OutT>(out, vr, vec_ok, nvalid);
-    store8<OutT>(out + plane, vg, vec_ok, nvalid);
-    store8<OutT>(out + 2 * plane, vb, vec_ok, nvalid);
+    store8<OutT>(out + cstride, vg, vec_ok, nvalid);
+    store8<OutT>(out + 2 * cstride, vb, vec_ok, nvalid);
 }
 
 template <typename OutT, int PX, bool MASK = false>
@@ -271,14 +297,17 @@ bool launch_ratio(int R, dim3 grid, hipStream_t s, const K1Args &a)
 
 int preprocess_common(rva_ctx *ctx, bool nv12, int mode, const void *const *p0, const void *const *p1,
                       const int32_t *pitches, int n, int src_w, int src_h, void *out, int out_dtype, int dst_w,
-                      int dst_h, rva_letterbox *meta_out, hipStream_t stream, const void *const *masks = nullptr)
+                      int dst_h, rva_letterbox *meta_out, hipStream_t stream, const void *const *masks = nullptr,
+                      int norm = 0, int layout = 0)
 {
     const bool clip = mode != 0;   // modes 1 and 2 stretch to the full target, no letterbox border
     if (!ctx) return RVA_ERR_ARG;
     if (!p0 || (nv12 && !p1) || !pitches || n <= 0 || n > RVA_MAX_BATCH || !out || src_w <= 0 || src_h <= 0 ||
         dst_w <= 0 || dst_h <= 0)
         return rva_fail(ctx, RVA_ERR_ARG, "preprocess: bad argument (1 <= n <= %d)", RVA_MAX_BATCH);
-    if (out_dtype != RVA_F16 && out_dtype != RVA_F32) return rva_fail(ctx, RVA_ERR_ARG, "out_dtype must be RVA_F16|RVA_F32");
+    if (out_dtype == RVA_F64 ? !(mode == 1 && norm == RVA_NORM_IMAGENET_F64) : (out_dtype != RVA_F16 && out_dtype != RVA_F32))
+        return rva_fail(ctx, RVA_ERR_ARG, "out_dtype must be RVA_F16|RVA_F32 (RVA_F64 only with RVA_NORM_IMAGENET_F64)");
+    if (norm < 0 || norm > 2 || layout < 0 || layout > 1) return rva_fail(ctx, RVA_ERR_ARG, "bad norm / layout");
     if (nv12 && ((src_w | src_h) & 1)) return rva_fail(ctx, RVA_ERR_ARG, "NV12 surfaces need even dimensions");
     rva_letterbox m;
     if (clip) {  // stretch to the full target (temporal_detector.py:344), no border
@@ -310,7 +339,10 @@ int preprocess_common(rva_ctx *ctx, bool nv12, int mode, const void *const *p0, 
         mask_aligned = mask_aligned && ((uintptr_t)a.mask[i] % 8 == 0);
     }
     mask_aligned = mask_aligned && src_w % 8 == 0;
-    const size_t osz = mode == 2 ? 1 : (out_dtype == RVA_F16 ? 2 : 4);
+    const size_t osz = mode == 2 ? 1 : (out_dtype == RVA_F16 ? 2 : out_dtype == RVA_F32 ? 4 : 8);
+    a.norm = norm;
+    a.fstride = layout == RVA_LAYOUT_CNHW ? (long)dst_w * dst_h : 3L * dst_w * dst_h;
+    a.cstride = layout == RVA_LAYOUT_CNHW ? (long)n * dst_w * dst_h : (long)dst_w * dst_h;
     const bool out_aligned = ((uintptr_t)out % 16 == 0) && ((dst_w * osz) % 16 == 0);
 
     // integer-ratio fast path
@@ -353,6 +385,10 @@ int preprocess_common(rva_ctx *ctx, bool nv12, int mode, const void *const *p0, 
         else k1_generic<NV, MD, float><<<grid, 256, 0, stream>>>(a);                       \
     } while (0)
     if (mode == 2) { if (nv12) RVA_LAUNCH_GENERIC(true, 2); else RVA_LAUNCH_GENERIC(false, 2); }
+    else if (clip && out_dtype == RVA_F64) {
+        if (nv12) k1_generic<true, 1, double><<<grid, 256, 0, stream>>>(a);
+        else k1_generic<false, 1, double><<<grid, 256, 0, stream>>>(a);
+    }
     else if (nv12 && clip) RVA_LAUNCH_GENERIC(true, 1);
     else if (nv12) RVA_LAUNCH_GENERIC(true, 0);
     else if (clip) RVA_LAUNCH_GENERIC(false, 1);
@@ -395,6 +431,22 @@ int rva_preprocess_clip_bgr_batch(rva_ctx *ctx, const void *const *frames, const
 {
     return preprocess_common(ctx, false, 1, frames, nullptr, row_bytes, n, src_w, src_h, out, out_dtype, dst_w, dst_h,
                              nullptr, (hipStream_t)stream);
+}
+
+int rva_preprocess_frames_nv12_batch(rva_ctx *ctx, const void *const *y_ptrs, const void *const *uv_ptrs,
+                                     const int32_t *pitches, int n, int src_w, int src_h, void *out, int out_dtype,
+                                     int dst_w, int dst_h, int norm, int layout, rva_stream_t stream)
+{
+    return preprocess_common(ctx, true, 1, y_ptrs, uv_ptrs, pitches, n, src_w, src_h, out, out_dtype, dst_w, dst_h,
+                             nullptr, (hipStream_t)stream, nullptr, norm, layout);
+}
+
+int rva_preprocess_frames_bgr_batch(rva_ctx *ctx, const void *const *frames, const int32_t *row_bytes, int n, int src_w,
+                                    int src_h, void *out, int out_dtype, int dst_w, int dst_h, int norm, int layout,
+                                    rva_stream_t stream)
+{
+    return preprocess_common(ctx, false, 1, frames, nullptr, row_bytes, n, src_w, src_h, out, out_dtype, dst_w, dst_h,
+                             nullptr, (hipStream_t)stream, nullptr, norm, layout);
 }
 
 // ---- ROI mask + downsample in front of the detector ------------------------------------------

@@ -65,10 +65,15 @@ def create_detector(config: DetectorConfig) -> BaseDetector:
     model_type = config.model_type.lower()
     if backend in HIP_BACKENDS:
         if model_type in TEMPORAL_MODELS:
-            if model_type != "cnn_lstm":
-                raise ValueError(f"Temporal model type '{model_type}' not implemented by the hip backend")
-            from .temporal import HipCNNLSTMDetector
-            return HipCNNLSTMDetector(config)
+            from .temporal import HipCNN3DDetector, HipCNNLSTMDetector, HipConvGRUDetector
+            if model_type == "cnn_lstm":
+                return HipCNNLSTMDetector(config)
+            if model_type == "conv_gru":
+                return HipConvGRUDetector(config)
+            return HipCNN3DDetector(config)       # "3d_cnn", and "slow_fast" as in the reference (detector.py:70-74)
+        if model_type == "resnet":
+            from .classify import HipResNetDetector
+            return HipResNetDetector(config)
         if model_type in ("yolov5", "yolov8"):
             return HipYoloDetector(config)
         raise ValueError(f"Model type '{model_type}' not supported with backend '{config.backend}'")

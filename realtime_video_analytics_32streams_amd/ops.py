@@ -97,6 +97,55 @@ def preprocess_nv12(surfaces: Sequence[Nv12Surface], dst_hw=(640, 640), half: bo
     return (out, None) if clip else (out, meta)
 
 
+_FRAME_DT = {torch.float16: N.RVA_F16, torch.float32: N.RVA_F32, torch.float64: N.RVA_F64}
+
+
+def preprocess_frames(frames: Sequence, dst_hw=(224, 224), norm: int = N.NORM_IMAGENET_F32, layout: int = N.LAYOUT_NCHW,
+                      dtype: torch.dtype = torch.float32, out: Optional[torch.Tensor] = None,
+                      ctx: Optional[N.Context] = None) -> torch.Tensor:
+    """Frame pre-process of the classification / temporal heads (``rva_preprocess_frames_*``): stretch
+    resize, RGB, /255, (x-mean)/std with the constants and precision ``norm`` names.  ``frames``: NV12 surfaces or
+    device BGR uint8 ``[h,w,3]`` tensors of one geometry.  Returns ``[n,3,H,W]`` (``LAYOUT_NCHW``) or ``[3,n,H,W]``
+    (``LAYOUT_CNHW``, the 3D-CNN clip layout)."""
+    ctx = ctx or context()
+    n = len(frames)
+    if n == 0 or n > N.RVA_MAX_BATCH:
+        raise ValueError(f"1..{N.RVA_MAX_BATCH} frames per call")
+    H, W = int(dst_hw[0]), int(dst_hw[1])
+    shape = (n, 3, H, W) if layout == N.LAYOUT_NCHW else (3, n, H, W)
+    nv12 = isinstance(frames[0], Nv12Surface)
+    dev = frames[0].y.device if nv12 else frames[0].device
+    if out is None:
+        out = torch.empty(shape, dtype=dtype, device=dev)
+    _require_cuda(out, "output tensor")
+    assert out.is_contiguous() and out.dtype == dtype and tuple(out.shape) == shape
+    L = N.lib()
+    if nv12:
+        w, h = frames[0].width, frames[0].height
+        for s in frames:
+            _require_cuda(s.y, "NV12 surface")
+            if (s.width, s.height) != (w, h):
+                raise ValueError("all surfaces of one launch must share one geometry")
+        yp, _k1 = N.ptr_array([s.y.data_ptr() for s in frames])
+        up, _k2 = N.ptr_array([s.uv.data_ptr() for s in frames])
+        pp, _k3 = N.i32_array([s.pitch for s in frames])
+        rc = L.rva_preprocess_frames_nv12_batch(ctx.handle, yp, up, pp, n, w, h, C.c_void_p(out.data_ptr()), _FRAME_DT[dtype],
+                                                W, H, norm, layout, _stream_ptr())
+    else:
+        h, w = int(frames[0].shape[0]), int(frames[0].shape[1])
+        for f in frames:
+            _require_cuda(f, "BGR frame")
+            assert f.dtype == torch.uint8 and f.dim() == 3 and f.shape[2] == 3 and f.stride(2) == 1 and f.stride(1) == 3
+            if (int(f.shape[0]), int(f.shape[1])) != (h, w):
+                raise ValueError("all frames of one launch must share one geometry")
+        fp, _k1 = N.ptr_array([f.data_ptr() for f in frames])
+        rb, _k2 = N.i32_array([int(f.stride(0)) for f in frames])
+        rc = L.rva_preprocess_frames_bgr_batch(ctx.handle, fp, rb, n, w, h, C.c_void_p(out.data_ptr()), _FRAME_DT[dtype], W, H,
+                                               norm, layout, _stream_ptr())
+    ctx.check(rc, "rva_preprocess_frames_batch")
+    return out
+
+
 def resize_nv12_to_bgr(surfaces: Sequence[Nv12Surface], dst_wh: Tuple[int, int], out: Optional[torch.Tensor] = None,
                        ctx: Optional[N.Context] = None) -> torch.Tensor:
     """apply_roi (if a surface carries a mask) + downsample (utils/frame_filter.py:43-57): uint8 BGR images

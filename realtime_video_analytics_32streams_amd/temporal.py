@@ -19,12 +19,13 @@ from __future__ import annotations
 import logging
 from collections import deque
 from dataclasses import dataclass
-from typing import Deque, Dict, List, Optional, Tuple
+from typing import Deque, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
 import torch.nn as nn
 
+from . import _native as N
 from . import ops
 from .config import DetectorConfig
 from .detector import Detection
@@ -85,34 +86,79 @@ class CnnLstmNet(nn.Module):
         return self.head(out[:, -1])
 
 
-class HipCNNLSTMDetector:
-    """Duck-typed like the reference's temporal detectors: ``.config`` and ``.predict(packet)``."""
+class Cnn3dNet(nn.Module):
+    """The 3D-CNN the reference exports (scripts/convert_temporal_model_to_onnx.py:91-121): three Conv3d-BN-ReLU
+    stages with (1,2,2) / (2,2,2) max-pools, global average pool, linear head.  Input ``[B,3,T,H,W]``."""
+
+    def __init__(self, num_classes: int = 400):
+        super().__init__()
+        self.conv3d = nn.Sequential(
+            nn.Conv3d(3, 64, 3, padding=1), nn.BatchNorm3d(64), nn.ReLU(inplace=True), nn.MaxPool3d((1, 2, 2), (1, 2, 2)),
+            nn.Conv3d(64, 128, 3, padding=1), nn.BatchNorm3d(128), nn.ReLU(inplace=True), nn.MaxPool3d(2, 2),
+            nn.Conv3d(128, 256, 3, padding=1), nn.BatchNorm3d(256), nn.ReLU(inplace=True), nn.AdaptiveAvgPool3d(1))
+        self.fc = nn.Linear(256, num_classes)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.fc(self.conv3d(x).flatten(1))
+
+
+class _HipTemporalDetector:
+    """Shared body of the temporal heads, duck-typed like the reference's (``.config`` and ``.predict(packet)``):
+    clip buffering (temporal_detector.py:58-120), per-frame pre-process on arrival into an HBM ring, top-5 of the
+    raw model output (:392-424, :596-641, :760-799).  Subclasses fix the pre-process constants (``NORM``), the clip
+    layout the network takes and the default input size."""
+
+    NORM = N.NORM_IMAGENET_F32
+    CLIP_LAYOUT = "TCHW"                  # "TCHW": [1,T,3,H,W] (CNN-LSTM, ConvGRU); "CTHW": [1,3,T,H,W] (3D-CNN)
+    DEFAULT_HW = (224, 224)
 
     def __init__(self, config: DetectorConfig, net: Optional[nn.Module] = None, seed: int = 1,
-                 device: Optional[int] = None):
+                 device: Optional[int] = None, infer_fn=None):
         self.config = config
         self.ctx = ops.context(device)
         self.device = torch.device("cuda", self.ctx.device)
-        self.input_hw = (int(config.input_size[0]), int(config.input_size[1])) if config.input_size else (224, 224)
+        self.input_hw = (int(config.input_size[0]), int(config.input_size[1])) if config.input_size else self.DEFAULT_HW
         self.sched = ClipSchedule(config.sequence_length, config.sequence_stride, config.temporal_overlap)
         self.sequence_step = self.sched.step
         self.half = bool(config.half)
-        if net is None:
-            st = torch.random.get_rng_state()
-            torch.manual_seed(seed)
-            net = CnnLstmNet(config.num_action_classes)
-            torch.random.set_rng_state(st)
-        self.net = net.eval().to(self.device)
-        self.net = self.net.half() if self.half else self.net.float()
+        self._infer_fn = infer_fn
+        self.net = None
+        if infer_fn is None:
+            if net is None:
+                st = torch.random.get_rng_state()
+                torch.manual_seed(seed)
+                net = self._default_net()
+                torch.random.set_rng_state(st)
+            self.net = net.eval().to(self.device)
+            self.net = self.net.to(self._frame_dtype())
         self._buf: Dict[str, Deque] = {}
         self._ring: Dict[str, torch.Tensor] = {}
         self._free: Dict[str, List[int]] = {}
 
+    # -- per-head hooks ---------------------------------------------------------------------------
+    def _default_net(self) -> nn.Module:
+        raise NotImplementedError
+
+    def _frame_dtype(self) -> torch.dtype:
+        return torch.float16 if self.half else torch.float32
+
+    # -- reference-shaped pre-process of a whole clip (parity surface for _preprocess_sequence) -----
+    def preprocess_sequence(self, frames: Sequence) -> torch.Tensor:
+        """``_preprocess_sequence`` of the reference for device frames: ``[1,T,3,H,W]`` or ``[1,3,T,H,W]``."""
+        layout = N.LAYOUT_CNHW if self.CLIP_LAYOUT == "CTHW" else N.LAYOUT_NCHW
+        dev = [self._to_device(f) for f in frames]
+        return ops.preprocess_frames(dev, self.input_hw, self.NORM, layout, self._frame_dtype(), ctx=self.ctx).unsqueeze(0)
+
+    def _to_device(self, frame):
+        if isinstance(frame, ops.Nv12Surface):
+            return frame
+        t = torch.from_numpy(np.ascontiguousarray(frame)) if isinstance(frame, np.ndarray) else frame
+        return t.to(self.device).contiguous()
+
     def _state(self, name: str):
         if name not in self._buf:
-            dt = torch.float16 if self.half else torch.float32
             self._buf[name] = deque()
-            self._ring[name] = torch.empty((self.sched.need, 3, *self.input_hw), dtype=dt, device=self.device)
+            self._ring[name] = torch.empty((self.sched.need, 3, *self.input_hw), dtype=self._frame_dtype(), device=self.device)
             self._free[name] = list(range(self.sched.need))
         return self._buf[name], self._ring[name], self._free[name]
 
@@ -123,14 +169,10 @@ class HipCNNLSTMDetector:
             free.append(buf[0][1])
         slot = free.pop()
         frame = packet.frame
-        if isinstance(frame, ops.Nv12Surface):   # pre-process on arrival, straight into the ring slot
-            ops.preprocess_nv12([frame], self.input_hw, self.half, out=ring[slot:slot + 1], clip=True, ctx=self.ctx)
-            hw = (frame.height, frame.width)
-        else:
-            t = torch.from_numpy(np.ascontiguousarray(frame)) if isinstance(frame, np.ndarray) else frame
-            ops.preprocess_bgr([t.to(self.device).contiguous()], self.input_hw, self.half, out=ring[slot:slot + 1],
-                               clip=True, ctx=self.ctx)
-            hw = (int(frame.shape[0]), int(frame.shape[1]))
+        hw = (frame.height, frame.width) if isinstance(frame, ops.Nv12Surface) else (int(frame.shape[0]), int(frame.shape[1]))
+        # pre-process on arrival, straight into the ring slot
+        ops.preprocess_frames([self._to_device(frame)], self.input_hw, self.NORM, N.LAYOUT_NCHW, self._frame_dtype(),
+                              out=ring[slot:slot + 1], ctx=self.ctx)
         full = len(buf) == self.sched.need
         clip, dropped = self.sched.push(buf, (packet.frame_id, slot, hw))
         for k, item in enumerate(dropped):
@@ -142,8 +184,11 @@ class HipCNNLSTMDetector:
 
     def _predict_sequence(self, name: str, ring: torch.Tensor, clip) -> List[Detection]:
         idx = torch.tensor([c[1] for c in clip], device=self.device)
+        x = ring.index_select(0, idx)                                   # [T,3,H,W]
+        x = (x.permute(1, 0, 2, 3).contiguous() if self.CLIP_LAYOUT == "CTHW" else x).unsqueeze(0)
         with torch.inference_mode():
-            out = self.net(ring.index_select(0, idx).unsqueeze(0)).float().flatten().cpu().numpy()
+            raw = self._infer_fn(x) if self._infer_fn is not None else self.net(x)
+        out = raw.float().flatten().cpu().numpy()
         top_k = min(5, len(out))
         order = np.argsort(out, kind="stable")[-top_k:][::-1]     # temporal_detector.py:396-398
         h, w = clip[0][2]
@@ -159,3 +204,38 @@ class HipCNNLSTMDetector:
                                               action_label=label, temporal_score=float(conf),
                                               sequence_start_frame=clip[0][0], sequence_end_frame=clip[-1][0]))
         return dets
+
+
+class HipCNNLSTMDetector(_HipTemporalDetector):
+    """CNN-LSTM head (temporal_detector.py:150-426): float32 ImageNet normalisation, clips ``[1,T,3,H,W]``."""
+
+    def _default_net(self) -> nn.Module:
+        return CnnLstmNet(self.config.num_action_classes)
+
+
+class HipCNN3DDetector(_HipTemporalDetector):
+    """3D-CNN head (temporal_detector.py:429-641; also what the reference instantiates for ``slow_fast``,
+    detector.py:70-74): mean 0.45 / std 0.225, clips ``[1,3,T,H,W]``, default input 112x112 (:544)."""
+
+    NORM = N.NORM_VIDEO_F32
+    CLIP_LAYOUT = "CTHW"
+    DEFAULT_HW = (112, 112)
+
+    def _default_net(self) -> nn.Module:
+        return Cnn3dNet(self.config.num_action_classes)
+
+
+class HipConvGRUDetector(_HipTemporalDetector):
+    """ConvGRU head (temporal_detector.py:644-799).  Its pre-process holds the ImageNet constants in float64 arrays, so
+    the normalisation runs in float64 and the clip is float64 unless ``half`` (:741-752).  The reference has no
+    architecture for this head (it only loads an OpenVINO/ONNX file), so a network -- ``net`` taking ``[1,T,3,H,W]`` --
+    or an ``infer_fn`` must be supplied; constructing the detector without one fails like a missing model file."""
+
+    NORM = N.NORM_IMAGENET_F64
+
+    def _frame_dtype(self) -> torch.dtype:
+        return torch.float16 if self.half else torch.float64
+
+    def _default_net(self) -> nn.Module:
+        raise RuntimeError("ConvGRU: the reference defines no architecture for this head; pass net=... or infer_fn=... "
+                           f"(model_path '{self.config.model_path}' cannot be loaded offline)")

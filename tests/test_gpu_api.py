@@ -156,8 +156,13 @@ def test_detector_self_parity_fp16_gpu_vs_fp32_cpu():
 def test_create_detector_dispatch():
     assert isinstance(create_detector(_cfg()), HipYoloDetector)
     assert isinstance(create_detector(_cfg(model_type="cnn_lstm", model_path="x.onnx", sequence_length=4)), HipCNNLSTMDetector)
-    with pytest.raises(ValueError):
-        create_detector(_cfg(model_type="3d_cnn", model_path="x.onnx"))
+    from realtime_video_analytics_32streams_amd.classify import HipResNetDetector
+    from realtime_video_analytics_32streams_amd.temporal import HipCNN3DDetector
+    assert isinstance(create_detector(_cfg(model_type="3d_cnn", model_path="x.onnx", sequence_length=4)), HipCNN3DDetector)
+    assert isinstance(create_detector(_cfg(model_type="slow_fast", model_path="x.onnx", sequence_length=4)), HipCNN3DDetector)  # detector.py:70-74
+    assert isinstance(create_detector(_cfg(model_type="resnet", model_path="x.onnx")), HipResNetDetector)
+    with pytest.raises(RuntimeError):          # no architecture / file for ConvGRU: fails like a missing model
+        create_detector(_cfg(model_type="conv_gru", model_path="x.onnx", sequence_length=4))
 
 
 def test_cnn_lstm_detector_clips_and_scores():
@@ -189,3 +194,75 @@ def test_cnn_lstm_detector_clips_and_scores():
     d = dets[0]
     assert d.bbox_xyxy == (0.0, 0.0, 3840.0, 2160.0) and d.frame_id == 6 and d.sequence_start_frame == 0
     assert d.sequence_end_frame == 6 and d.action_label == f"a{d.class_id}" and d.temporal_score == d.confidence
+
+
+def test_cnn3d_detector_clip_layout_and_scores():
+    """3D-CNN head: mean 0.45 / std 0.225, clip [1,3,T,H,W], default 112x112; same buffering and top-5 rule."""
+    from realtime_video_analytics_32streams_amd.temporal import Cnn3dNet, HipCNN3DDetector
+    cfg = _cfg(model_type="3d_cnn", model_path="x.onnx", sequence_length=4, sequence_stride=1, temporal_overlap=0.5,
+               confidence_threshold=-1e9, num_action_classes=400)
+    torch.manual_seed(3)
+    net = Cnn3dNet(400).eval()
+    det = HipCNN3DDetector(cfg, net=copy.deepcopy(net))
+    assert det.input_hw == (112, 112)
+    st = StreamConfig(name="cam", url="x")
+    frames = [synth.make_bgr(60 + f, 320, 180) for f in range(6)]
+    fired = {}
+    for f, img in enumerate(frames):
+        out = det.predict(FramePacket(st, img, f, 0.0))
+        if out:
+            fired[f] = out
+    assert sorted(fired) == [3, 5]                           # need = 4 frames, step = 2
+    x = orc.preprocess_norm_frames(frames[:4], 112, 112, 1, 1, layout=1)           # [3,T,H,W]
+    seq = det.preprocess_sequence(frames[:4])
+    assert tuple(seq.shape) == (1, 3, 4, 112, 112) and np.array_equal(seq.cpu().numpy()[0].view(np.uint32), x.view(np.uint32))
+    with torch.inference_mode():
+        want = net(torch.from_numpy(x)[None]).flatten().numpy()
+    top = np.argsort(want)[-5:][::-1]
+    assert [d.class_id for d in fired[3]] == top.tolist()
+    assert np.allclose([d.confidence for d in fired[3]], want[top], atol=1e-3)
+    assert fired[3][0].bbox_xyxy == (0.0, 0.0, 320.0, 180.0) and fired[3][0].sequence_end_frame == 3
+
+
+def test_convgru_detector_float64_clip():
+    """ConvGRU head: the clip handed to the network is float64 (float16 with half), normalised in float64."""
+    from realtime_video_analytics_32streams_amd.temporal import HipConvGRUDetector
+    seen = {}
+
+    def infer(x):
+        seen["x"] = x
+        return x.double().mean((1, 3, 4)).flatten()[:3].repeat(2)            # any [K] vector
+    cfg = _cfg(model_type="conv_gru", model_path="x.onnx", sequence_length=2, sequence_stride=1, temporal_overlap=0.0,
+               confidence_threshold=-1e9, num_action_classes=6, input_size=[64, 64])
+    det = HipConvGRUDetector(cfg, infer_fn=infer)
+    st = StreamConfig(name="cam", url="x")
+    frames = [synth.make_bgr(70 + f, 200, 120) for f in range(2)]
+    assert det.predict(FramePacket(st, frames[0], 0, 0.0)) == []
+    out = det.predict(FramePacket(st, frames[1], 1, 0.0))
+    x = seen["x"]
+    assert x.dtype == torch.float64 and tuple(x.shape) == (1, 2, 3, 64, 64)
+    want = orc.preprocess_norm_frames(frames, 64, 64, 2, 2)
+    assert np.array_equal(x.cpu().numpy()[0].view(np.uint64), want.view(np.uint64))
+    assert len(out) == 5 and out[0].frame_id == 1
+
+
+def test_resnet_classifier_topk():
+    """ResNet classification head: float32 ImageNet pre-process, top-K of the raw output, full-frame boxes."""
+    from realtime_video_analytics_32streams_amd.classify import HipResNetDetector, ResNet18
+    cfg = _cfg(model_type="resnet", model_path="x.onnx", confidence_threshold=-1e9, resnet_top_k=3, resnet_num_classes=50)
+    torch.manual_seed(5)
+    net = ResNet18(50).eval()
+    det = HipResNetDetector(cfg, net=copy.deepcopy(net))
+    st = StreamConfig(name="cam", url="x")
+    frames = [synth.make_bgr(80 + f, 300, 200) for f in range(2)]
+    res = det.predict_batch([FramePacket(st, f, i, 0.0) for i, f in enumerate(frames)])
+    x = orc.preprocess_norm_frames(frames, 224, 224, 0, 1)
+    with torch.inference_mode():
+        want = net(torch.from_numpy(x)).numpy()
+    for i in range(2):
+        top = np.argsort(want[i])[-3:][::-1]
+        assert [d.class_id for d in res[i]] == top.tolist()
+        assert np.allclose([d.confidence for d in res[i]], want[i][top], atol=2e-3)
+        assert res[i][0].bbox_xyxy == (0.0, 0.0, 300.0, 200.0) and res[i][0].frame_id == i
+    hi = HipResNetDetector(_cfg(model_type="resnet", model_path="x.onnx", confidence_threshold=1e9), net=copy.deepcopy(net))
+    assert hi.predict(FramePacket(st, frames[0], 0, 0.0)) == []

@@ -333,3 +333,28 @@ def test_preprocess_clip_frames(half):
     out, _ = ops.preprocess_bgr([torch.from_numpy(f).to(DEV)], (112, 112), half=half, clip=True)
     want = orc.preprocess_clip_frame(bgr=f, tw=112, th=112, half=half)
     assert np.array_equal(out.cpu().numpy()[0].view(view), want.view(view))
+
+
+# ---- frame pre-process of the ResNet / 3D-CNN / ConvGRU heads -----------------------------------------
+@pytest.mark.parametrize("norm,dtype", [(0, "f16"), (0, "f32"), (1, "f16"), (1, "f32"), (2, "f16"), (2, "f32"), (2, "f64")])
+@pytest.mark.parametrize("layout", [0, 1], ids=["TCHW", "CTHW"])
+def test_preprocess_frames_norms_and_layouts(norm, dtype, layout):
+    """rva_preprocess_frames_* against the oracle, bit-for-bit (float16 / float32 / float64 words), NV12 4K surfaces
+    and odd-sized BGR frames, both clip layouts."""
+    tdt = {"f16": torch.float16, "f32": torch.float32, "f64": torch.float64}[dtype]
+    odt = {"f16": 0, "f32": 1, "f64": 2}[dtype]
+    surf = [synth.make_nv12(20 + i, 3840, 2160, tick=i) for i in range(3)]
+    out = ops.preprocess_frames([ops.Nv12Surface.from_numpy(y, uv, 3840, 2160) for y, uv in surf], (112, 112), norm, layout, tdt)
+    want = orc.preprocess_norm_frames(surf, 112, 112, norm, odt, layout=layout, nv12_wh=(3840, 2160))
+    assert out.shape == want.shape
+    assert np.array_equal(out.cpu().numpy().view(np.uint8), want.view(np.uint8))
+    frames = [synth.make_bgr(30 + i, 333, 201) for i in range(2)]
+    out = ops.preprocess_frames([torch.from_numpy(f).to(DEV) for f in frames], (56, 40), norm, layout, tdt)
+    want = orc.preprocess_norm_frames(frames, 40, 56, norm, odt, layout=layout)
+    assert np.array_equal(out.cpu().numpy().view(np.uint8), want.view(np.uint8))
+
+
+def test_preprocess_frames_rejects_f64_outside_convgru():
+    f = torch.from_numpy(synth.make_bgr(1, 64, 48)).to(DEV)
+    with pytest.raises(RuntimeError):
+        ops.preprocess_frames([f], (32, 32), 0, 0, torch.float64)

@@ -113,3 +113,37 @@ def test_preprocess_letterbox_layout():
     assert np.all(out[:, :14] == pad) and np.all(out[:, 50:] == pad)
     rs = orc.resize_linear(bgr, 64, 36)
     assert np.array_equal(out[0, 14:50], rs[..., 2].astype(np.float32) * np.float32(1 / 255.0))  # R plane first
+
+
+# ---- normalisation arithmetic of the remaining heads --------------------------------------------------
+@pytest.mark.parametrize("norm", [0, 1, 2], ids=["imagenet_f32", "video_f32", "imagenet_f64"])
+@pytest.mark.parametrize("out_dtype", [0, 1, 2], ids=["f16", "f32", "f64"])
+def test_oracle_frame_normalisation_matches_numpy_semantics(norm, out_dtype):
+    """The oracle's C normalise step against numpy evaluating the reference's own expressions (same dtypes, same
+    operation order) on the oracle-resized uint8 image: temporal_detector.py:350-354 (norm 0, also detector.py:988-993),
+    :570-573 (norm 1), :741-743 (norm 2, float64 constant arrays).  Pins the float arithmetic incl. the float64 ->
+    float16 single rounding; the resize in front of it stays unpinned (no OpenCV here)."""
+    if out_dtype == 2 and norm != 2:
+        pytest.skip("the reference produces float64 only in the ConvGRU pre-process")
+    rng = np.random.default_rng(11 + norm)
+    bgr = rng.integers(0, 256, (45, 70, 3), dtype=np.uint8)
+    tw, th = 32, 24
+    rs = orc.resize_bgr(bgr, tw, th)
+    image = rs[..., ::-1].astype(np.float32) / 255.0                     # BGR2RGB; astype(float32) / 255.0
+    if norm == 0:
+        mean = np.array([0.485, 0.456, 0.406], dtype=np.float32); std = np.array([0.229, 0.224, 0.225], dtype=np.float32)
+    elif norm == 1:
+        mean = np.array([0.45, 0.45, 0.45], dtype=np.float32); std = np.array([0.225, 0.225, 0.225], dtype=np.float32)
+    else:
+        mean = np.array([0.485, 0.456, 0.406]); std = np.array([0.229, 0.224, 0.225])
+    image = (image - mean) / std
+    assert image.dtype == (np.float64 if norm == 2 else np.float32)
+    want = np.ascontiguousarray(np.transpose(image, (2, 0, 1)))
+    want = want.astype({0: np.float16, 1: np.float32, 2: np.float64}[out_dtype])
+    got = orc.preprocess_norm_frames([bgr], tw, th, norm, out_dtype)[0]
+    assert got.dtype == want.dtype and np.array_equal(got.view(np.uint8), want.view(np.uint8))
+    # clip layouts: [T,C,H,W] stacks frames on axis 0, [C,T,H,W] is its transpose (temporal_detector.py:583-590)
+    frames = [bgr, bgr[::-1].copy(), bgr[:, ::-1].copy()]
+    tchw = orc.preprocess_norm_frames(frames, tw, th, norm, out_dtype, layout=0)
+    cthw = orc.preprocess_norm_frames(frames, tw, th, norm, out_dtype, layout=1)
+    assert np.array_equal(np.transpose(tchw, (1, 0, 2, 3)), cthw) and np.array_equal(tchw[0], got)
