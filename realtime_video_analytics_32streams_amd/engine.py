@@ -68,16 +68,25 @@ class FusedYoloV8:
             self.autotune()
 
     # -- weight preparation ---------------------------------------------------------------------------
-    def _conv_params(self, conv: torch.nn.Conv2d):
-        w = conv.weight.detach().float()                      # [Cout, Cin, k, k]
+    def _conv_params(self, conv):
+        """``conv``: one Conv2d, or a list of Conv2d with equal Cin / kernel / stride whose outputs are concatenated
+        along the channel axis (one launch for sibling convolutions that read the same tensor)."""
+        convs = list(conv) if isinstance(conv, (list, tuple)) else [conv]
+        conv = convs[0]
+        assert all(c.kernel_size == conv.kernel_size and c.stride == conv.stride and c.in_channels == conv.in_channels
+                   for c in convs)
+        w = torch.cat([c.weight.detach().float() for c in convs], 0)        # [Cout, Cin, k, k]
         cout, cin, k, _ = w.shape
         cpad = self.L.rva_conv_cout_pad(cout)
         cinp = (cin + 31) // 32 * 32
         wp = torch.zeros((cpad, k * k, cinp), dtype=torch.float16)
         wp[:cout, :, :cin] = w.permute(0, 2, 3, 1).reshape(cout, k * k, cin).half()
         bp = torch.zeros((cpad,), dtype=torch.float32)
-        if conv.bias is not None:
-            bp[:cout] = conv.bias.detach().float()
+        o = 0
+        for c in convs:
+            if c.bias is not None:
+                bp[o:o + c.out_channels] = c.bias.detach().float()
+            o += c.out_channels
         wp, bp = wp.to(self.dev).contiguous(), bp.to(self.dev).contiguous()
         self._keep += [wp, bp]
         return wp, bp, cin, cout, k, conv.stride[0]
@@ -89,9 +98,11 @@ class FusedYoloV8:
 
     # -- step emitters --------------------------------------------------------------------------------
     def _conv(self, mod, src: _View, dst: _View, h: int, w: int, res: Optional[_View] = None):
-        conv = mod.conv if isinstance(mod, ConvBnAct) else mod
-        act = 1 if isinstance(mod, ConvBnAct) and mod.act else 0
-        wp, bp, cin, cout, k, stride = self._conv_params(conv)
+        mods = list(mod) if isinstance(mod, (list, tuple)) else [mod]
+        acts = {1 if isinstance(m, ConvBnAct) and m.act else 0 for m in mods}
+        assert len(acts) == 1, "fused sibling convolutions must share the activation"
+        act = acts.pop()
+        wp, bp, cin, cout, k, stride = self._conv_params([m.conv if isinstance(m, ConvBnAct) else m for m in mods])
         assert cin == src.ch and cout == dst.ch, (cin, src.ch, cout, dst.ch)
         B, L, ctx = self.B, self.L, self.ctx
 
@@ -207,12 +218,17 @@ class FusedYoloV8:
             m = B * hh * ww
             cb = box[0].conv.out_channels
             cc = cls[0].conv.out_channels
-            b1 = _View(self._buf(m, cb), 0, cb); b2 = _View(self._buf(m, cb), 0, cb)
+            # the first convolution of the box and of the class branch read the same feature map: one launch with
+            # Cout = cb + cc writing one buffer, the branches continue on its channel slices
+            first = _View(self._buf(m, cb + cc), 0, cb + cc)
+            b1, k1 = first.sub(0, cb), first.sub(cb, cc)
+            b2 = _View(self._buf(m, cb), 0, cb)
             bo = _View(self._buf(m, 64), 0, 64)
-            k1 = _View(self._buf(m, cc), 0, cc); k2 = _View(self._buf(m, cc), 0, cc)
+            k2 = _View(self._buf(m, cc), 0, cc)
             ko = _View(self._buf(m, self.nc), 0, self.nc)
-            self._conv(box[0], feat, b1, hh, ww); self._conv(box[1], b1, b2, hh, ww); self._conv(box[2], b2, bo, hh, ww)
-            self._conv(cls[0], feat, k1, hh, ww); self._conv(cls[1], k1, k2, hh, ww); self._conv(cls[2], k2, ko, hh, ww)
+            self._conv([box[0], cls[0]], feat, first, hh, ww)
+            self._conv(box[1], b1, b2, hh, ww); self._conv(box[2], b2, bo, hh, ww)
+            self._conv(cls[1], k1, k2, hh, ww); self._conv(cls[2], k2, ko, hh, ww)
             B_, out, nc = B, self.out, self.nc
 
             def head(stream, bo=bo, ko=ko, hh=hh, ww=ww, a0=a0, stride=stride):
