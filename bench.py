@@ -131,23 +131,30 @@ def main():
     for i in range(S):
         slot[pipe.slots[i]] = i
     post_ref = [None]
-    use_graph = (not args.no_graph) and world == 1 and args.engine == "fused"
+    use_graph = (not args.no_graph) and args.engine == "fused"
 
-    def tail(k, tensor, meta, e=None):
-        """Everything after K1: network -> K2/K3 -> K4 -> ids -> D2H snapshot (slot = tick parity)."""
+    def tail_a(tensor, meta, e=None):
+        """After K1, rank-local part: network -> K2/K3 -> K4 update (capturable: no collective, no host sync)."""
         with torch.inference_mode():
             raw = det._infer(tensor)
             if e: e[2].record()
             post = det._postprocess_device(raw, [meta])
             if e: e[3].record()
         dt.update_from_post(slot, post, dcfg.confidence_threshold)               # K4 (+F1 filter)
+        post_ref[0] = post
+
+    def tail_b(k, e=None):
+        """Global track ids (all-gather of the new-track counts when streams are sharded) -> D2H snapshot."""
         if id_sync is None:
             dt.assign_ids()
         else:
             dt.assign_ids(id_sync.all_gather_counts(dt.new_counts_tensor()[:S]), pipe.global_index)
         if e: e[4].record()
         dt.snapshot_async(k & 1)
-        post_ref[0] = post
+
+    def tail(k, tensor, meta, e=None):
+        tail_a(tensor, meta, e)
+        tail_b(k, e)
 
     graphs, done = [None, None], [torch.cuda.Event(), torch.cuda.Event()]
     if use_graph:
@@ -157,8 +164,13 @@ def main():
         for par in (0, 1):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                tail(par, tensor0, meta0)
+                if world == 1:
+                    tail(par, tensor0, meta0)          # single GPU: ids + snapshot ride in the graph too
+                else:
+                    tail_a(tensor0, meta0)             # sharded streams: the id exchange (RCCL) stays outside
             graphs[par] = g
+            if world > 1:
+                break                                  # the rank-local part does not depend on the tick parity
         torch.cuda.synchronize()
 
     def enqueue(k):
@@ -169,8 +181,12 @@ def main():
             e[0].record()
             tensor, meta = det._preprocess([p.frame for p in packets])           # K1 (eager, bracketed by events)
             e[1].record()
-        if use_graph:
+        if use_graph and world == 1:
             graphs[k & 1].replay()
+            done[k & 1].record()
+        elif use_graph:
+            graphs[0].replay()
+            tail_b(k)
             done[k & 1].record()
         else:
             tail(k, tensor, meta, e)
