@@ -86,6 +86,11 @@ int rva_preprocess_bgr_batch(rva_ctx *ctx, const void *const *frames, const int3
                              int src_w, int src_h, void *out, int out_dtype, int dst_w, int dst_h,
                              rva_letterbox *meta_out, rva_stream_t stream);
 
+/* Measurement aid (bench.py roofline leg): the NEXT integer-ratio K1 launch of this context is issued with
+ * hipExtLaunchKernelGGL so that the two HIP events (hipEvent_t handles created with timing enabled) are written by
+ * the kernel's own dispatch -- they bracket exactly that kernel.  One-shot; pass NULL, NULL to cancel. */
+int rva_profile_next_preprocess(rva_ctx *ctx, void *start_event, void *stop_event);
+
 /* Clip-frame pre-process -- replaces the per-frame body of CNNLSTMDetector._preprocess_sequence
  * (temporal_detector.py:340-359): stretch-resize to (dst_w, dst_h), BGR2RGB, /255.0, (x-mean)/std
  * (ImageNet constants), CHW; out[n, 3, dst_h, dst_w] in out_dtype (float32 math, cast last). */

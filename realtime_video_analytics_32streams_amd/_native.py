@@ -98,6 +98,7 @@ def lib() -> C.CDLL:
                                                      C.c_int, _P]),
         "rva_preprocess_clip_bgr_batch": (C.c_int, [_P, pp, i32p, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int,
                                                     C.c_int, _P]),
+        "rva_profile_next_preprocess": (C.c_int, [_P, _P, _P]),
         "rva_preprocess_frames_nv12_batch": (C.c_int, [_P, pp, pp, i32p, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int,
                                                        C.c_int, C.c_int, C.c_int, _P]),
         "rva_preprocess_frames_bgr_batch": (C.c_int, [_P, pp, i32p, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int,
@@ -149,7 +150,7 @@ def lib() -> C.CDLL:
 EXPORTS = [
     "rva_abi_version", "rva_create", "rva_destroy", "rva_last_error", "rva_reserve", "rva_letterbox_meta",
     "rva_preprocess_nv12_batch", "rva_preprocess_bgr_batch", "rva_preprocess_clip_nv12_batch",
-    "rva_preprocess_clip_bgr_batch", "rva_preprocess_frames_nv12_batch", "rva_preprocess_frames_bgr_batch", "rva_postprocess_batch", "rva_post_status", "rva_tracker_create",
+    "rva_preprocess_clip_bgr_batch", "rva_profile_next_preprocess", "rva_preprocess_frames_nv12_batch", "rva_preprocess_frames_bgr_batch", "rva_postprocess_batch", "rva_post_status", "rva_tracker_create",
     "rva_tracker_destroy", "rva_tracker_update_f32", "rva_tracker_update_f64", "rva_tracker_new_counts",
     "rva_tracker_assign_ids", "rva_tracker_read", "rva_tracker_read_all", "rva_tracker_snapshot_async",
     "rva_tracker_snapshot_fetch", "rva_tracker_state",

@@ -37,6 +37,8 @@ struct rva_ctx {
     int32_t *post_flags = nullptr;// [1]
     // resize tap tables keyed by (src, dst) per axis
     std::map<uint64_t, rva_resize_table> taps_x, taps_y;
+    // one-shot profiling events for the next K1 (integer-ratio) launch: rva_profile_next_preprocess
+    hipEvent_t k1_start = nullptr, k1_stop = nullptr;
 };
 
 inline int rva_fail(rva_ctx *ctx, int code, const char *fmt, ...)

@@ -22,6 +22,8 @@
 
 #include <cstdlib>
 
+#include <hip/hip_ext.h>
+
 #include "rva_internal.h"
 
 namespace {
@@ -282,15 +284,24 @@ __global__ void __launch_bounds__(256) k1_generic(K1Args a)
     store8<OutT>(out + 2 * cstride, vb, vec_ok, nvalid);
 }
 
+// kernel launch with optional start / stop events written by the dispatch itself (hipExtLaunchKernelGGL): the pair
+// brackets exactly this kernel, without the inter-launch gap two hipEventRecord calls around it would include
+template <int R, typename OutT, int PX, bool MASK>
+void launch_ratio_r(dim3 grid, hipStream_t s, const K1Args &a, hipEvent_t e0, hipEvent_t e1)
+{
+    if (e0 && e1) hipExtLaunchKernelGGL((k1_ratio<R, OutT, PX, MASK>), grid, dim3(256), 0, s, e0, e1, 0, a);
+    else k1_ratio<R, OutT, PX, MASK><<<grid, 256, 0, s>>>(a);
+}
+
 template <typename OutT, int PX, bool MASK = false>
-bool launch_ratio(int R, dim3 grid, hipStream_t s, const K1Args &a)
+bool launch_ratio(int R, dim3 grid, hipStream_t s, const K1Args &a, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr)
 {
     switch (R) {
-        case 1: k1_ratio<1, OutT, PX, MASK><<<grid, 256, 0, s>>>(a); return true;
-        case 2: k1_ratio<2, OutT, PX, MASK><<<grid, 256, 0, s>>>(a); return true;
-        case 3: k1_ratio<3, OutT, PX, MASK><<<grid, 256, 0, s>>>(a); return true;
-        case 4: k1_ratio<4, OutT, PX, MASK><<<grid, 256, 0, s>>>(a); return true;
-        case 6: k1_ratio<6, OutT, PX, MASK><<<grid, 256, 0, s>>>(a); return true;
+        case 1: launch_ratio_r<1, OutT, PX, MASK>(grid, s, a, e0, e1); return true;
+        case 2: launch_ratio_r<2, OutT, PX, MASK>(grid, s, a, e0, e1); return true;
+        case 3: launch_ratio_r<3, OutT, PX, MASK>(grid, s, a, e0, e1); return true;
+        case 4: launch_ratio_r<4, OutT, PX, MASK>(grid, s, a, e0, e1); return true;
+        case 6: launch_ratio_r<6, OutT, PX, MASK>(grid, s, a, e0, e1); return true;
         default: return false;
     }
 }
@@ -360,10 +371,13 @@ int preprocess_common(rva_ctx *ctx, bool nv12, int mode, const void *const *p0, 
                           out_dtype == RVA_F16;
         const int PXv = px16 ? 16 : 8;
         dim3 grid(rva_ceil_div((dst_w / PXv) * dst_h, 256), n);
-        const bool ok = any_mask ? (out_dtype == RVA_F16 ? launch_ratio<__half, 8, true>(R, grid, stream, a)
-                                                          : launch_ratio<float, 8, true>(R, grid, stream, a))
-                      : px16 ? launch_ratio<__half, 16>(R, grid, stream, a)
-                             : (out_dtype == RVA_F16 ? launch_ratio<__half, 8>(R, grid, stream, a) : launch_ratio<float, 8>(R, grid, stream, a));
+        hipEvent_t e0 = ctx->k1_start, e1 = ctx->k1_stop;
+        ctx->k1_start = ctx->k1_stop = nullptr;                // one-shot
+        const bool ok = any_mask ? (out_dtype == RVA_F16 ? launch_ratio<__half, 8, true>(R, grid, stream, a, e0, e1)
+                                                          : launch_ratio<float, 8, true>(R, grid, stream, a, e0, e1))
+                      : px16 ? launch_ratio<__half, 16>(R, grid, stream, a, e0, e1)
+                             : (out_dtype == RVA_F16 ? launch_ratio<__half, 8>(R, grid, stream, a, e0, e1)
+                                                     : launch_ratio<float, 8>(R, grid, stream, a, e0, e1));
         if (ok) {
             RVA_HIP(ctx, hipGetLastError());
             return RVA_OK;
@@ -431,6 +445,14 @@ int rva_preprocess_clip_bgr_batch(rva_ctx *ctx, const void *const *frames, const
 {
     return preprocess_common(ctx, false, 1, frames, nullptr, row_bytes, n, src_w, src_h, out, out_dtype, dst_w, dst_h,
                              nullptr, (hipStream_t)stream);
+}
+
+int rva_profile_next_preprocess(rva_ctx *ctx, void *start_event, void *stop_event)
+{
+    if (!ctx) return RVA_ERR_ARG;
+    ctx->k1_start = (hipEvent_t)start_event;
+    ctx->k1_stop = (hipEvent_t)stop_event;
+    return RVA_OK;
 }
 
 int rva_preprocess_frames_nv12_batch(rva_ctx *ctx, const void *const *y_ptrs, const void *const *uv_ptrs,

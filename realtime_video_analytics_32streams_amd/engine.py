@@ -229,10 +229,10 @@ class FusedYoloV8:
             self._conv([box[0], cls[0]], feat, first, hh, ww)
             self._conv(box[1], b1, b2, hh, ww); self._conv(box[2], b2, bo, hh, ww)
             self._conv(cls[1], k1, k2, hh, ww); self._conv(cls[2], k2, ko, hh, ww)
-            B_, out, nc = B, self.out, self.nc
+            B_, nc = B, self.nc
 
             def head(stream, bo=bo, ko=ko, hh=hh, ww=ww, a0=a0, stride=stride):
-                ctx.check(L.rva_yolo_head_f16(ctx.handle, bo.ptr, bo.ld, ko.ptr, ko.ld, _p(out), B_, hh, ww, nc, A, a0,
+                ctx.check(L.rva_yolo_head_f16(ctx.handle, bo.ptr, bo.ld, ko.ptr, ko.ld, _p(self.out), B_, hh, ww, nc, A, a0,
                                               C.c_float(stride), stream), "yolo_head")
             self._steps.append(head)
             a0 += hh * ww
@@ -276,6 +276,17 @@ class FusedYoloV8:
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         for step in self._steps:
             step(stream)
+        return self.out
+
+    def use_output(self, index: int) -> torch.Tensor:
+        """Select which of two result tensors the head kernels write (``index`` 0 / 1; the second one is allocated
+        on first use).  A pipelined caller alternates them per tick, so the post-process of tick k can still read its
+        head tensor on another HIP stream while the network of tick k+1 runs."""
+        if not hasattr(self, "_outs"):
+            self._outs = [self.out, None]
+        if self._outs[index] is None:
+            self._outs[index] = torch.empty_like(self._outs[0])
+        self.out = self._outs[index]
         return self.out
 
     @property
