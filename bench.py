@@ -138,114 +138,26 @@ def main():
     rctx = ops.context(local)
     n_tracks = 0
     dt = trk.device_tracker
-    slot = [-1] * dt.n_streams
-    for i in range(S):
-        slot[pipe.slots[i]] = i
-    post_ref = [None]
     use_graph = (not args.no_graph) and args.engine == "fused"
-
-    def tail_a(tensor, meta, e=None):
-        """After K1, rank-local part: network -> K2/K3 -> K4 update (capturable: no collective, no host sync)."""
-        with torch.inference_mode():
-            raw = det._infer(tensor)
-            if e: e[2].record()
-            post = det._postprocess_device(raw, [meta])
-            if e: e[3].record()
-        dt.update_from_post(slot, post, dcfg.confidence_threshold)               # K4 (+F1 filter)
-        post_ref[0] = post
-
-    def tail_b(k, e=None):
-        """Global track ids (all-gather of the new-track counts when streams are sharded) -> D2H snapshot."""
-        if id_sync is None:
-            dt.assign_ids()
-        else:
-            dt.assign_ids(id_sync.all_gather_counts(dt.new_counts_tensor()[:S]), pipe.global_index)
-        if e: e[4].record()
-        dt.snapshot_async(k & 1)
-
-    def tail(k, tensor, meta, e=None):
-        tail_a(tensor, meta, e)
-        tail_b(k, e)
-
-    # Two HIP streams with fixed roles: A = K1 + detector network, B = K2/K3 -> K4 -> ids -> D2H snapshot.  The part on
-    # B is latency-bound (32 small blocks per launch), so tick k's post-process / tracker runs UNDER tick k+1's network
-    # instead of in front of it.  The head tensor is double-buffered (engine.use_output); the tracker state is only
-    # touched on B, in tick order.
-    graphs, done = [None, None], [torch.cuda.Event(), torch.cuda.Event()]
-    net_graphs, net_done = [None, None], [torch.cuda.Event(), torch.cuda.Event()]
-    k1_done = [torch.cuda.Event(), torch.cuda.Event()]
-    sA = torch.cuda.current_stream()
-    sB = torch.cuda.Stream(device=dev) if use_graph else sA
-    raws = [None, None]
-    if use_graph:
-        with torch.inference_mode():
-            tensor0, meta0 = det._preprocess([src._ring[0] for src in sources])
-        plan = next(iter(det._plans.values()))
-        for par in (0, 1):
-            plan.use_output(par)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                with torch.inference_mode():
-                    raws[par] = det._infer(tensor0)                     # network only, writes head tensor `par`
-            net_graphs[par] = g
-        torch.cuda.synchronize()
-        for par in (0, 1):
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                with torch.inference_mode():
-                    post = det._postprocess_device(raws[par], [meta0])
-                dt.update_from_post(slot, post, dcfg.confidence_threshold)   # K4 (+F1 filter)
-                post_ref[0] = post
-                if world == 1:
-                    tail_b(par)                                          # single GPU: ids + snapshot ride in the graph
-            graphs[par] = g
-        torch.cuda.synchronize()
+    from realtime_video_analytics_32streams_amd.pipeline import PipelinedTicks
+    runner = PipelinedTicks(pipe, depth=args.depth, use_graph=use_graph)
 
     def enqueue(k):
         t_enq[k] = time.perf_counter()
-        packets = [src.next_packet() for src in sources]
-        e = ev[k]
-        par = k & 1
-        with torch.inference_mode():
-            e[0].record()
-            if k % K1_SAMPLE_EVERY == 0:
-                N.lib().rva_profile_next_preprocess(rctx.handle, evk[k][0].cuda_event, evk[k][1].cuda_event)
-            tensor, meta = det._preprocess([p.frame for p in packets])           # K1 (eager, bracketed by events)
-            e[1].record()
-        if use_graph:
-            k1_done[par].record(sA)
-            if k >= 2:
-                sA.wait_event(done[par])          # tick k-2 has finished reading head tensor `par`
-            net_graphs[par].replay()
-            net_done[par].record(sA)
-            if args.depth == 1:
-                issue_post(k, None)
-            elif k >= 1:
-                # tick k-1's post-process / tracker starts once K1 of tick k is through: K1 (the HBM-bound kernel the
-                # roofline is quoted on) runs alone, the latency-bound tail then hides under the network of tick k
-                issue_post(k - 1, k1_done[par])
-        else:
-            tail(k, tensor, meta, e)
-
-    def issue_post(k, after):
-        par = k & 1
-        with torch.cuda.stream(sB):
-            sB.wait_event(net_done[par])
-            if after is not None:
-                sB.wait_event(after)
-            graphs[par].replay()
-            if world > 1:
-                tail_b(k)                         # sharded streams: the id exchange (RCCL) stays outside the graph
-            done[par].record(sB)
+        arm = None
+        if k % K1_SAMPLE_EVERY == 0:
+            arm = lambda: N.lib().rva_profile_next_preprocess(rctx.handle, evk[k][0].cuda_event, evk[k][1].cuda_event)
+        runner.submit(events=ev[k], before_k1=arm)
 
     def finish(k):
-        if use_graph:
-            done[k & 1].synchronize()
-            tables = dt.snapshot_fetch(k & 1, wait=False)
-        else:
-            tables = dt.snapshot_fetch(k & 1)                                     # tracks visible to the host
+        _, tables = runner.collect()
         lat[k] = time.perf_counter() - t_enq[k]
         return sum(t["n"] for t in tables)
+
+    # graph capture + one full tick through the runner, outside the timed region
+    runner.submit()
+    runner.collect()
+    torch.cuda.synchronize()
 
     barrier()
     t_begin = time.perf_counter()
@@ -258,10 +170,8 @@ def main():
         for k in range(1, K):
             enqueue(k)
             n_tracks += finish(k - 1)
-        if use_graph:
-            issue_post(K - 1, None)
         n_tracks += finish(K - 1)
-    post = post_ref[0]
+    post = runner.last_post
     barrier()
     elapsed = time.perf_counter() - t_begin
     if world > 1:
@@ -276,13 +186,10 @@ def main():
         k1_ms = k1_bracket_ms
     if use_graph:   # per-stage split of the captured part: eager pass AFTER the timed region (informational)
         ev2 = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(20)]
+        eager = PipelinedTicks(pipe, depth=1, use_graph=False)
         for k in range(20):
-            packets = [src.next_packet() for src in sources]
-            with torch.inference_mode():
-                ev2[k][0].record()
-                tensor, meta = det._preprocess([p.frame for p in packets])
-                ev2[k][1].record()
-            tail(k, tensor, meta, ev2[k])
+            eager.submit(events=ev2[k])
+            eager.collect()
         torch.cuda.synchronize()
         stage = np.array([[e[i].elapsed_time(e[i + 1]) for i in range(1, 4)] for e in ev2])
     else:

@@ -196,3 +196,151 @@ class TickPipeline:
                 self.adaptive[i].update(emitted.get(self.names[i], 0), len(tracks[self.names[i]]))
         self._tick += 1
         return TickResult(self._tick - 1, tracks, emitted, time.perf_counter() - t0)
+
+
+class PipelinedTicks:
+    """Throughput mode of :class:`TickPipeline`: ``depth`` ticks in flight, no host round trip inside a tick.
+
+    Two HIP streams with fixed roles.  Stream A: K1 (eager) + the detector network; stream B: K2/K3 -> K4 -> global ids
+    -> D2H snapshot of the track tables (slot = tick parity).  With ``use_graph`` the network and the part on B are
+    replayed from captured hipGraphs (one per head-tensor parity; the fused plan never allocates or synchronises).  With
+    sharded streams (``pipe.id_sync``) the RCCL exchange of new-track counts, ``k4_assign_ids`` and the snapshot follow
+    B's graph eagerly.  B's work for tick k is released once K1 of tick k+1 is through, so the latency-bound tail hides
+    under the next network and K1 runs alone.  Same results as ``TickPipeline.tick`` (same kernels, same order per
+    stream); the pre-detector gates are host decisions per tick and are not supported here.
+
+    ``submit()`` enqueues one tick and returns its ticket; ``collect()`` returns ``(ticket, tables)`` of the oldest
+    outstanding tick, ``tables[slot]`` being the arrays of ``DeviceTracker.snapshot_fetch``.
+    """
+
+    def __init__(self, pipe: TickPipeline, depth: int = 2, use_graph: bool = True):
+        if any(pipe._motion_on) or any(a.enabled for a in pipe.adaptive) or pipe.downsample_ratio < 0.999 or \
+                any(s.roi_polygons for s in pipe.streams):
+            raise NotImplementedError("PipelinedTicks runs the ungated path (motion / adaptive-fps / ROI / downsample off)")
+        if depth not in (1, 2):
+            raise ValueError("depth must be 1 or 2 (two snapshot slots, two head tensors)")
+        self.pipe, self.depth = pipe, depth
+        self.det, self.dt = pipe.detector, pipe.tracker.device_tracker
+        self.world_sharded = pipe.id_sync is not None
+        self.slot = [-1] * self.dt.n_streams
+        for i in range(len(pipe.streams)):
+            self.slot[pipe.slots[i]] = i
+        self.use_graph = bool(use_graph) and self.det.engine == "fused" and self.det.half
+        self.sA = torch.cuda.current_stream()
+        self.sB = torch.cuda.Stream(device=self.det.device) if self.use_graph else self.sA
+        self._next, self._oldest = 0, 0
+        self._done = [torch.cuda.Event(), torch.cuda.Event()]
+        self._net_done = [torch.cuda.Event(), torch.cuda.Event()]
+        self._k1_done = [torch.cuda.Event(), torch.cuda.Event()]
+        self._net_graphs, self._post_graphs = [None, None], [None, None]
+        self._posted = -1                     # last tick whose stream-B part has been issued
+        self.last_post = None
+        self._captured = False
+
+    # -- pieces of a tick -------------------------------------------------------------------------------------
+    def _post_part(self, raw, meta, events=None):
+        with torch.inference_mode():
+            post = self.det._postprocess_device(raw, [meta])
+        if events: events[3].record()
+        self.dt.update_from_post(self.slot, post, self.det.config.confidence_threshold)       # K4 (+F1 filter)
+        self.last_post = post
+
+    def _ids_and_snapshot(self, k, events=None):
+        p = self.pipe
+        if p.id_sync is None:
+            self.dt.assign_ids()
+        else:
+            n = len(p.streams)
+            self.dt.assign_ids(p.id_sync.all_gather_counts(self.dt.new_counts_tensor()[:n]), p.global_index)
+        if events: events[4].record()
+        self.dt.snapshot_async(k & 1)
+
+    def _capture(self, frames):
+        det = self.det
+        with torch.inference_mode():
+            tensor0, meta0 = det._preprocess(frames)
+            det._infer(tensor0)                                    # builds + autotunes the plan outside any capture
+        plan = det._plans[(int(tensor0.shape[0]), int(tensor0.shape[2]), int(tensor0.shape[3]))]
+        torch.cuda.synchronize()
+        raws = [None, None]
+        for par in (0, 1):
+            plan.use_output(par)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                with torch.inference_mode():
+                    raws[par] = det._infer(tensor0)                # network only, writes head tensor `par`
+            self._net_graphs[par] = g
+        torch.cuda.synchronize()
+        for par in (0, 1):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._post_part(raws[par], meta0)
+                if not self.world_sharded:
+                    self._ids_and_snapshot(par)                    # single GPU: ids + snapshot ride in the graph
+            self._post_graphs[par] = g
+        torch.cuda.synchronize()
+        self._captured = True
+
+    def _issue_post(self, k, after):
+        par = k & 1
+        with torch.cuda.stream(self.sB):
+            self.sB.wait_event(self._net_done[par])
+            if after is not None:
+                self.sB.wait_event(after)
+            self._post_graphs[par].replay()
+            if self.world_sharded:
+                self._ids_and_snapshot(k)                          # the id exchange (RCCL) stays outside the graph
+            self._done[par].record(self.sB)
+        self._posted = k
+
+    # -- API ----------------------------------------------------------------------------------------------------
+    def submit(self, packets: Optional[Sequence[FramePacket]] = None, events=None, before_k1=None) -> int:
+        """Enqueue one tick.  ``events``: optional list of 5 timing events (before K1, after K1, after the network,
+        after K2/K3, after ids) -- the last three are only recorded in the non-graph path.  ``before_k1``: optional
+        callable run right before the K1 launch (bench.py arms the dispatch-level profiling events with it)."""
+        if self._next - self._oldest >= self.depth:
+            raise RuntimeError("collect() the oldest tick first")
+        k = self._next
+        par = k & 1
+        if packets is None:
+            packets = [src.next_packet() for src in self.pipe.sources]
+        frames = [p.frame for p in packets]
+        if self.use_graph and not self._captured:
+            self._capture(frames)
+        with torch.inference_mode():
+            if events: events[0].record()
+            if before_k1: before_k1()
+            tensor, meta = self.det._preprocess(frames)            # K1
+            if events: events[1].record()
+        if self.use_graph:
+            self._k1_done[par].record(self.sA)
+            if k >= 2:
+                self.sA.wait_event(self._done[par])                # tick k-2 has finished reading head tensor `par`
+            self._net_graphs[par].replay()
+            self._net_done[par].record(self.sA)
+            if self.depth == 1:
+                self._issue_post(k, None)
+            elif k >= 1 and self._posted < k - 1:
+                self._issue_post(k - 1, self._k1_done[par])        # K1 of this tick first, then the previous tail
+        else:
+            with torch.inference_mode():
+                raw = self.det._infer(tensor)
+            if events: events[2].record()
+            self._post_part(raw, meta, events)
+            self._ids_and_snapshot(k, events)
+        self._next += 1
+        return k
+
+    def collect(self):
+        if self._oldest >= self._next:
+            raise RuntimeError("nothing in flight")
+        k = self._oldest
+        if self.use_graph:
+            if self._posted < k:
+                self._issue_post(k, None)                          # no younger tick was submitted: release the tail now
+            self._done[k & 1].synchronize()
+            tables = self.dt.snapshot_fetch(k & 1, wait=False)
+        else:
+            tables = self.dt.snapshot_fetch(k & 1)                 # tracks visible to the host
+        self._oldest += 1
+        return k, tables

@@ -266,3 +266,41 @@ def test_resnet_classifier_topk():
         assert res[i][0].bbox_xyxy == (0.0, 0.0, 300.0, 200.0) and res[i][0].frame_id == i
     hi = HipResNetDetector(_cfg(model_type="resnet", model_path="x.onnx", confidence_threshold=1e9), net=copy.deepcopy(net))
     assert hi.predict(FramePacket(st, frames[0], 0, 0.0)) == []
+
+
+@pytest.mark.parametrize("depth,graph", [(1, False), (2, False), (1, True), (2, True)], ids=["d1-eager", "d2-eager", "d1-graph", "d2-graph"])
+def test_pipelined_ticks_equal_synchronous_ticks(depth, graph):
+    """The throughput mode (two HIP streams, captured hipGraphs, two ticks in flight) yields the same track tables,
+    ids included, as TickPipeline.tick() on the same frames -- same detector object (same autotuned plan) on both
+    sides, separate trackers."""
+    from realtime_video_analytics_32streams_amd.pipeline import PipelinedTicks
+    streams, det, trk, srcs = _make_pipe(4)
+    sync = TickPipeline(streams, det, trk, sources=srcs)
+    trk2 = IouTracker(TrackerConfig(max_age=5, max_iou_distance=0.5, min_hits=1), max_streams=4, capacity=512)
+    srcs2 = [SyntheticNv12Stream(s, index=i, n_unique=3) for i, s in enumerate(streams)]
+    for s in srcs2:
+        s.open_sync()
+    runner = PipelinedTicks(TickPipeline(streams, det, trk2, sources=srcs2), depth=depth, use_graph=graph)
+    T = 7
+    want = []
+    for _ in range(T):
+        r = sync.tick()
+        want.append({n: [(t.track_id, t.class_id, t.age, t.hits, t.confidence, t.bbox_xyxy) for t in v] for n, v in r.tracks.items()})
+    got = []
+
+    def take():
+        _, tables = runner.collect()
+        names = [s.name for s in streams]
+        tr = trk2.tracks_from_tables(names, [tables[runner.pipe.slots[i]] for i in range(len(streams))])
+        got.append({n: [(t.track_id, t.class_id, t.age, t.hits, t.confidence, t.bbox_xyxy) for t in v] for n, v in zip(names, tr)})
+    if depth == 1:
+        for _ in range(T):
+            runner.submit(); take()
+    else:
+        runner.submit()
+        for _ in range(1, T):
+            runner.submit(); take()
+        take()
+    assert got == want and sum(len(v) for d in got for v in d.values()) > 0
+    with pytest.raises(RuntimeError):
+        runner.collect()
