@@ -226,8 +226,10 @@ class PipelinedTicks:
         for i in range(len(pipe.streams)):
             self.slot[pipe.slots[i]] = i
         self.use_graph = bool(use_graph) and self.det.engine == "fused" and self.det.half
+        self.two_streams = self.det.engine == "fused" and self.det.half      # needs the plan's second head tensor
         self.sA = torch.cuda.current_stream()
-        self.sB = torch.cuda.Stream(device=self.det.device) if self.use_graph else self.sA
+        self.sB = torch.cuda.Stream(device=self.det.device) if self.two_streams else self.sA
+        self._pending = [None, None]          # eager mode: (raw, meta, events) of the tick whose stream-B part is due
         self._next, self._oldest = 0, 0
         self._done = [torch.cuda.Event(), torch.cuda.Event()]
         self._net_done = [torch.cuda.Event(), torch.cuda.Event()]
@@ -287,9 +289,14 @@ class PipelinedTicks:
             self.sB.wait_event(self._net_done[par])
             if after is not None:
                 self.sB.wait_event(after)
-            self._post_graphs[par].replay()
-            if self.world_sharded:
-                self._ids_and_snapshot(k)                          # the id exchange (RCCL) stays outside the graph
+            if self.use_graph:
+                self._post_graphs[par].replay()
+                if self.world_sharded:
+                    self._ids_and_snapshot(k)                      # the id exchange (RCCL) stays outside the graph
+            else:
+                raw, meta, events = self._pending[par]
+                self._post_part(raw, meta, events)
+                self._ids_and_snapshot(k, events)
             self._done[par].record(self.sB)
         self._posted = k
 
@@ -312,11 +319,22 @@ class PipelinedTicks:
             if before_k1: before_k1()
             tensor, meta = self.det._preprocess(frames)            # K1
             if events: events[1].record()
-        if self.use_graph:
+        if self.two_streams:
             self._k1_done[par].record(self.sA)
             if k >= 2:
                 self.sA.wait_event(self._done[par])                # tick k-2 has finished reading head tensor `par`
-            self._net_graphs[par].replay()
+            if self.use_graph:
+                self._net_graphs[par].replay()
+            else:
+                with torch.inference_mode():
+                    plan = self.det._plans.get((int(tensor.shape[0]), int(tensor.shape[2]), int(tensor.shape[3])))
+                    if plan is None:
+                        self.det._infer(tensor)                    # builds + autotunes the plan
+                        plan = self.det._plans[(int(tensor.shape[0]), int(tensor.shape[2]), int(tensor.shape[3]))]
+                    plan.use_output(par)
+                    raw = self.det._infer(tensor)
+                if events: events[2].record()
+                self._pending[par] = (raw, meta, events)
             self._net_done[par].record(self.sA)
             if self.depth == 1:
                 self._issue_post(k, None)
@@ -335,7 +353,7 @@ class PipelinedTicks:
         if self._oldest >= self._next:
             raise RuntimeError("nothing in flight")
         k = self._oldest
-        if self.use_graph:
+        if self.two_streams:
             if self._posted < k:
                 self._issue_post(k, None)                          # no younger tick was submitted: release the tail now
             self._done[k & 1].synchronize()
