@@ -186,7 +186,7 @@ def main():
         k1_ms = k1_bracket_ms
     if use_graph:   # per-stage split of the captured part: eager pass AFTER the timed region (informational)
         ev2 = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(20)]
-        eager = PipelinedTicks(pipe, depth=1, use_graph=False)
+        eager = PipelinedTicks(pipe, depth=1, use_graph=False, overlap=False)
         for k in range(20):
             eager.submit(events=ev2[k])
             eager.collect()

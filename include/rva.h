@@ -204,7 +204,8 @@ int rva_tracker_read(rva_tracker *trk, int stream_id, int cap, int64_t *ids, int
                      rva_stream_t stream);
 
 /* Host-synchronous read-back of every stream at once: arrays are [n_streams, capacity(,4)],
- * counts[n_streams]; any pointer may be NULL. */
+ * counts[n_streams]; any pointer may be NULL.  Only rows [0, counts[s]) of stream s are written (one device
+ * kernel gathers the live rows into a pinned slot); the rest of the caller's arrays is left untouched. */
 int rva_tracker_read_all(rva_tracker *trk, int64_t *ids, int32_t *cls, int32_t *age, int32_t *hits,
                          double *conf, double *boxes, int32_t *last_det, int32_t *counts,
                          rva_stream_t stream);

@@ -44,6 +44,7 @@ struct rva_tracker {
     // pinned host staging
     int32_t *h_slot = nullptr, *h_offs = nullptr;
     void *h_read[2] = {nullptr, nullptr};   // pinned snapshot slots
+    void *h_read_dev[2] = {nullptr, nullptr};   // the same slots as the device sees them
     hipEvent_t snap_done[2] = {nullptr, nullptr};
     size_t h_read_bytes = 0;
     hipEvent_t staged = nullptr;  // completion of the last async copy out of h_slot/h_offs
@@ -296,7 +297,8 @@ int rva_tracker_create(rva_ctx *ctx, int n_streams, int capacity, int max_age, d
     RVA_HIP(ctx, hipEventCreateWithFlags(&t->staged, hipEventDisableTiming));
     t->h_read_bytes = sc * (8 + 32 + 8 + 4 + 4 + 4 + 4) + n_streams * 4 + 64 * 9;
     for (int i = 0; i < 2; ++i) {
-        RVA_HIP(ctx, hipHostMalloc(&t->h_read[i], t->h_read_bytes));
+        RVA_HIP(ctx, hipHostMalloc(&t->h_read[i], t->h_read_bytes, hipHostMallocMapped));
+        RVA_HIP(ctx, hipHostGetDevicePointer(&t->h_read_dev[i], t->h_read[i], 0));
         RVA_HIP(ctx, hipEventCreateWithFlags(&t->snap_done[i], hipEventDisableTiming));
     }
     RVA_HIP(ctx, hipMemset(t->n_tracks, 0, n_streams * 4));
@@ -407,16 +409,46 @@ static size_t snap_off(const rva_tracker *t, int section)
     return off;
 }
 
+// One launch instead of eight D2H copies: each block (= stream) writes the LIVE rows of its tables straight into the
+// pinned, device-mapped snapshot slot (same section layout, rows beyond n_tracks[s] are left untouched).  At ~13-120
+// tracks per stream that is tens of KB over PCIe instead of the full S x cap tables (2 MB at cap = 1024), and no
+// blit-kernel launches with host-side gaps between them.
+struct SnapArgs {
+    const int64_t *id; const double *box; const double *conf; const int32_t *cls, *age, *hits, *last_det, *n_tracks;
+    int64_t *h_id; double *h_box; double *h_conf; int32_t *h_cls, *h_age, *h_hits, *h_last, *h_n;
+    int cap;
+};
+
+__global__ void __launch_bounds__(256) k4_snapshot(SnapArgs a)
+{
+    const int s = blockIdx.x;
+    const int n = min(a.n_tracks[s], a.cap);
+    if (threadIdx.x == 0) a.h_n[s] = a.n_tracks[s];
+    const size_t base = (size_t)s * a.cap;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const size_t r = base + i;
+        a.h_id[r] = a.id[r];
+        a.h_conf[r] = a.conf[r];
+        a.h_cls[r] = a.cls[r];
+        a.h_age[r] = a.age[r];
+        a.h_hits[r] = a.hits[r];
+        a.h_last[r] = a.last_det[r];
+        reinterpret_cast<double2 *>(a.h_box)[2 * r] = reinterpret_cast<const double2 *>(a.box)[2 * r];
+        reinterpret_cast<double2 *>(a.h_box)[2 * r + 1] = reinterpret_cast<const double2 *>(a.box)[2 * r + 1];
+    }
+}
+
 int rva_tracker_snapshot_async(rva_tracker *t, int slot, rva_stream_t stream_)
 {
     if (!t || slot < 0 || slot > 1) return RVA_ERR_ARG;
     hipStream_t stream = (hipStream_t)stream_;
-    const size_t sc = (size_t)t->n_streams * t->cap;
-    char *h = (char *)t->h_read[slot];
-    const void *src[8] = {t->id, t->box, t->conf, t->cls, t->age, t->hits, t->last_det, t->n_tracks};
-    const size_t sizes[8] = {sc * 8, sc * 32, sc * 8, sc * 4, sc * 4, sc * 4, sc * 4, (size_t)t->n_streams * 4};
-    for (int i = 0; i < 8; ++i)
-        RVA_HIP(t->ctx, hipMemcpyAsync(h + snap_off(t, i), src[i], sizes[i], hipMemcpyDeviceToHost, stream));
+    char *h = (char *)t->h_read_dev[slot];
+    SnapArgs a{t->id, t->box, t->conf, t->cls, t->age, t->hits, t->last_det, t->n_tracks,
+               (int64_t *)(h + snap_off(t, 0)), (double *)(h + snap_off(t, 1)), (double *)(h + snap_off(t, 2)),
+               (int32_t *)(h + snap_off(t, 3)), (int32_t *)(h + snap_off(t, 4)), (int32_t *)(h + snap_off(t, 5)),
+               (int32_t *)(h + snap_off(t, 6)), (int32_t *)(h + snap_off(t, 7)), t->cap};
+    k4_snapshot<<<t->n_streams, 256, 0, stream>>>(a);
+    RVA_HIP(t->ctx, hipGetLastError());
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(stream, &cap);
     if (cap == hipStreamCaptureStatusNone)   // inside a graph capture the caller synchronises on the replay instead
@@ -429,16 +461,22 @@ int rva_tracker_snapshot_fetch(rva_tracker *t, int slot, int wait, int64_t *ids,
 {
     if (!t || slot < 0 || slot > 1) return RVA_ERR_ARG;
     if (wait) RVA_HIP(t->ctx, hipEventSynchronize(t->snap_done[slot]));
-    const size_t sc = (size_t)t->n_streams * t->cap;
     const char *h = (const char *)t->h_read[slot];
-    if (ids) std::memcpy(ids, h + snap_off(t, 0), sc * 8);
-    if (boxes) std::memcpy(boxes, h + snap_off(t, 1), sc * 32);
-    if (conf) std::memcpy(conf, h + snap_off(t, 2), sc * 8);
-    if (cls) std::memcpy(cls, h + snap_off(t, 3), sc * 4);
-    if (age) std::memcpy(age, h + snap_off(t, 4), sc * 4);
-    if (hits) std::memcpy(hits, h + snap_off(t, 5), sc * 4);
-    if (last_det) std::memcpy(last_det, h + snap_off(t, 6), sc * 4);
-    if (counts) std::memcpy(counts, h + snap_off(t, 7), (size_t)t->n_streams * 4);
+    const int32_t *hn = (const int32_t *)(h + snap_off(t, 7));
+    if (counts) std::memcpy(counts, hn, (size_t)t->n_streams * 4);
+    // only the live rows of every stream exist in the slot (k4_snapshot): copy those, leave the rest of the caller's
+    // [S][cap] arrays untouched
+    for (int s = 0; s < t->n_streams; ++s) {
+        const size_t n = (size_t)(hn[s] < t->cap ? (hn[s] > 0 ? hn[s] : 0) : t->cap), r = (size_t)s * t->cap;
+        if (!n) continue;
+        if (ids) std::memcpy(ids + r, h + snap_off(t, 0) + r * 8, n * 8);
+        if (boxes) std::memcpy(boxes + r * 4, h + snap_off(t, 1) + r * 32, n * 32);
+        if (conf) std::memcpy(conf + r, h + snap_off(t, 2) + r * 8, n * 8);
+        if (cls) std::memcpy(cls + r, h + snap_off(t, 3) + r * 4, n * 4);
+        if (age) std::memcpy(age + r, h + snap_off(t, 4) + r * 4, n * 4);
+        if (hits) std::memcpy(hits + r, h + snap_off(t, 5) + r * 4, n * 4);
+        if (last_det) std::memcpy(last_det + r, h + snap_off(t, 6) + r * 4, n * 4);
+    }
     return RVA_OK;
 }
 

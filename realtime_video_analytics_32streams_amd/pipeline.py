@@ -213,7 +213,7 @@ class PipelinedTicks:
     outstanding tick, ``tables[slot]`` being the arrays of ``DeviceTracker.snapshot_fetch``.
     """
 
-    def __init__(self, pipe: TickPipeline, depth: int = 2, use_graph: bool = True):
+    def __init__(self, pipe: TickPipeline, depth: int = 2, use_graph: bool = True, overlap: bool = True):
         if any(pipe._motion_on) or any(a.enabled for a in pipe.adaptive) or pipe.downsample_ratio < 0.999 or \
                 any(s.roi_polygons for s in pipe.streams):
             raise NotImplementedError("PipelinedTicks runs the ungated path (motion / adaptive-fps / ROI / downsample off)")
@@ -226,7 +226,8 @@ class PipelinedTicks:
         for i in range(len(pipe.streams)):
             self.slot[pipe.slots[i]] = i
         self.use_graph = bool(use_graph) and self.det.engine == "fused" and self.det.half
-        self.two_streams = self.det.engine == "fused" and self.det.half      # needs the plan's second head tensor
+        # ``overlap=False`` keeps everything on one stream (eager only): the per-stage timing pass of bench.py
+        self.two_streams = (overlap or self.use_graph) and self.det.engine == "fused" and self.det.half   # needs the second head tensor
         self.sA = torch.cuda.current_stream()
         self.sB = torch.cuda.Stream(device=self.det.device) if self.two_streams else self.sA
         self._pending = [None, None]          # eager mode: (raw, meta, events) of the tick whose stream-B part is due
