@@ -1019,6 +1019,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NSLOT 
     constexpr int PIECES = APIECES + WPIECES;
     constexpr int SLOTH = PIECES * 512;                   // halfs per ring slot
     constexpr int NP = (PIECES + 7) / 8;                  // pieces per wave per step (upper bound)
+    static_assert(NSLOT == 3 || NP <= 3 * FN, "the two-slot form issues one piece per (dx, i) MFMA group");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __half *ring = (__half *)smem;                        // [NSLOT][PIECES][16][32]
 
