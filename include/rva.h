@@ -255,6 +255,11 @@ int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *wei
                           int Cout, int ksize, int stride, int act, int variant, rva_stream_t stream);
 int rva_stem_conv_f16(rva_ctx *ctx, const void *in_planar, const void *weights, const float *bias,
                       void *out, int ldo, int batch, int H, int W, int Cout, rva_stream_t stream);
+/* SPPF's three chained 5x5/1 max pools in one launch: out1 = pool5(in), out2 = pool5(out1) = pool9(in),
+ * out3 = pool5(out2) = pool13(in) (stride 1, -inf padding), all three with row stride ldo.  H*W*64 bytes must fit LDS
+ * (H*W <= 2400); larger maps use rva_maxpool5_nhwc_f16 three times. */
+int rva_sppf_pool3_nhwc_f16(rva_ctx *ctx, const void *in, int ldi, void *out1, void *out2, void *out3, int ldo,
+                            int batch, int H, int W, int C, rva_stream_t stream);
 int rva_maxpool5_nhwc_f16(rva_ctx *ctx, const void *in, int ldi, void *out, int ldo, int batch, int H,
                           int W, int C, rva_stream_t stream);
 int rva_upsample2x_nhwc_f16(rva_ctx *ctx, const void *in, int ldi, void *out, int ldo, int batch, int H,

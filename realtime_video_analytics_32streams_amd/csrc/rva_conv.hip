@@ -872,6 +872,58 @@ __global__ void __launch_bounds__(256) k_stem(StemArgs a, const __half *__restri
 }
 
 // ---------------------------------------------------------------------------------------------------
+// The three chained 5x5 max pools of SPPF in one launch.  pool5(pool5(x)) = pool9(x) and pool5^3(x) = pool13(x)
+// (stride 1, -inf padding: the windows just grow), so all three outputs are separable running maxima of the same tile:
+// a block holds one image x 8 channels in LDS, does the row pass for window radii 2 / 4 / 6, then the column pass,
+// and writes y1, y2, y3 into their channel slices.  Replaces three dependent launches that each re-read 25 taps from L2.
+__global__ void __launch_bounds__(256) k_sppf_pool3(const __half *in, int ldi, __half *o1, __half *o2, __half *o3, int ldo,
+                                                    int H, int W, int C)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int HW = H * W, cg = C >> 3;
+    h8 *x = (h8 *)smem;                  // [HW]
+    h8 *r5 = x + HW, *r9 = r5 + HW, *r13 = r9 + HW;
+    const int b = blockIdx.x / cg, g = blockIdx.x - b * cg;
+    const size_t base = (size_t)b * HW;
+    for (int p = threadIdx.x; p < HW; p += 256) x[p] = *reinterpret_cast<const h8 *>(in + (base + p) * ldi + g * 8);
+    __syncthreads();
+    for (int p = threadIdx.x; p < HW; p += 256) {
+        const int y = p / W, xx = p - y * W;
+        h8 m = x[p];
+#pragma unroll
+        for (int d = 1; d <= 6; ++d) {
+            if (xx - d >= 0) m = __builtin_elementwise_max(m, x[p - d]);
+            if (xx + d < W) m = __builtin_elementwise_max(m, x[p + d]);
+            if (d == 2) r5[p] = m;
+            if (d == 4) r9[p] = m;
+        }
+        r13[p] = m;
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < HW; p += 256) {
+        const int y = p / W;
+        h8 m5 = r5[p], m9 = r9[p], m13 = r13[p];
+#pragma unroll
+        for (int d = 1; d <= 6; ++d) {
+            if (y - d >= 0) {
+                if (d <= 2) m5 = __builtin_elementwise_max(m5, r5[p - d * W]);
+                if (d <= 4) m9 = __builtin_elementwise_max(m9, r9[p - d * W]);
+                m13 = __builtin_elementwise_max(m13, r13[p - d * W]);
+            }
+            if (y + d < H) {
+                if (d <= 2) m5 = __builtin_elementwise_max(m5, r5[p + d * W]);
+                if (d <= 4) m9 = __builtin_elementwise_max(m9, r9[p + d * W]);
+                m13 = __builtin_elementwise_max(m13, r13[p + d * W]);
+            }
+        }
+        const size_t o = (base + p) * ldo + g * 8;
+        *reinterpret_cast<h8 *>(o1 + o) = m5;
+        *reinterpret_cast<h8 *>(o2 + o) = m9;
+        *reinterpret_cast<h8 *>(o3 + o) = m13;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // 5x5 stride-1 pad-2 max pool over a channel slice (C % 8 == 0): thread = (pixel, 8 channels)
 __global__ void __launch_bounds__(256) k_maxpool5(const __half *in, int ldi, __half *out, int ldo, int B, int H, int W, int C)
 {
@@ -1687,6 +1739,24 @@ int rva_maxpool5_nhwc_f16(rva_ctx *ctx, const void *in, int ldi, void *out, int 
     if (!ctx || !in || !out || C % 8 || ldi % 8 || ldo % 8) return rva_fail(ctx, RVA_ERR_ARG, "rva_maxpool5_nhwc_f16: bad argument");
     const long n = (long)batch * H * W * (C / 8);
     k_maxpool5<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream_>>>((const __half *)in, ldi, (__half *)out, ldo, batch, H, W, C);
+    RVA_HIP(ctx, hipGetLastError());
+    return RVA_OK;
+}
+
+int rva_sppf_pool3_nhwc_f16(rva_ctx *ctx, const void *in, int ldi, void *out1, void *out2, void *out3, int ldo, int batch,
+                            int H, int W, int C, rva_stream_t stream_)
+{
+    if (!ctx || !in || !out1 || !out2 || !out3 || C % 8 || ldi % 8 || ldo % 8 || batch <= 0 || H <= 0 || W <= 0)
+        return rva_fail(ctx, RVA_ERR_ARG, "rva_sppf_pool3_nhwc_f16: bad argument");
+    const size_t smem = (size_t)H * W * 16 * 4;
+    if (smem > 150 * 1024) return rva_fail(ctx, RVA_ERR_ARG, "rva_sppf_pool3_nhwc_f16: H*W too large for one LDS tile (use rva_maxpool5_nhwc_f16 x3)");
+    static bool attr = false;
+    if (!attr) {
+        RVA_HIP(ctx, hipFuncSetAttribute((const void *)k_sppf_pool3, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        attr = true;
+    }
+    k_sppf_pool3<<<batch * (C / 8), 256, smem, (hipStream_t)stream_>>>((const __half *)in, ldi, (__half *)out1, (__half *)out2,
+                                                                       (__half *)out3, ldo, H, W, C);
     RVA_HIP(ctx, hipGetLastError());
     return RVA_OK;
 }

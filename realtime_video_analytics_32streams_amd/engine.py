@@ -137,12 +137,20 @@ class FusedYoloV8:
         cat = _View(self._buf(m, 4 * c_), 0, 4 * c_)
         self._conv(mod.cv1, src, cat.sub(0, c_), h, w)
         B, L, ctx = self.B, self.L, self.ctx
-        for i in range(3):
-            s, d = cat.sub(i * c_, c_), cat.sub((i + 1) * c_, c_)
+        if h * w <= 2400:            # the three chained pools as one launch (pool9 / pool13 of the same LDS tile)
+            x, y1, y2, y3 = (cat.sub(i * c_, c_) for i in range(4))
 
-            def run(stream, s=s, d=d):
-                ctx.check(L.rva_maxpool5_nhwc_f16(ctx.handle, s.ptr, s.ld, d.ptr, d.ld, B, h, w, c_, stream), "maxpool5")
-            self._steps.append(run)
+            def run3(stream):
+                ctx.check(L.rva_sppf_pool3_nhwc_f16(ctx.handle, x.ptr, x.ld, y1.ptr, y2.ptr, y3.ptr, y1.ld, B, h, w, c_, stream),
+                          "sppf_pool3")
+            self._steps.append(run3)
+        else:
+            for i in range(3):
+                s, d = cat.sub(i * c_, c_), cat.sub((i + 1) * c_, c_)
+
+                def run(stream, s=s, d=d):
+                    ctx.check(L.rva_maxpool5_nhwc_f16(ctx.handle, s.ptr, s.ld, d.ptr, d.ld, B, h, w, c_, stream), "maxpool5")
+                self._steps.append(run)
         self._conv(mod.cv2, cat, dst, h, w)
 
     def _upsample(self, src: _View, dst: _View, h: int, w: int):

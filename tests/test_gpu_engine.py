@@ -116,6 +116,16 @@ def test_pool_upsample_head_primitives():
     ctx.check(L.rva_maxpool5_nhwc_f16(ctx.handle, C.c_void_p(x.data_ptr() + 2 * 64), 96, C.c_void_p(out.data_ptr()), 32, 2, 20, 20, 32, s))
     want = F.max_pool2d(x[..., 64:].permute(0, 3, 1, 2).float(), 5, 1, 2).permute(0, 2, 3, 1)
     assert torch.equal(out.float(), want)
+    # SPPF: three chained pools in one launch == pool5 applied three times (exact: max is exact in fp16)
+    for (hh, ww) in ((20, 20), (13, 17), (40, 40)):
+        xs = torch.randn((3, hh, ww, 16 + 4 * 24)).half().cuda()                      # [skip 16 | x | y1 | y2 | y3]
+        src = xs[..., 16:40]
+        ctx.check(L.rva_sppf_pool3_nhwc_f16(ctx.handle, C.c_void_p(xs.data_ptr() + 2 * 16), 112, C.c_void_p(xs.data_ptr() + 2 * 40),
+                                            C.c_void_p(xs.data_ptr() + 2 * 64), C.c_void_p(xs.data_ptr() + 2 * 88), 112, 3, hh, ww, 24, s))
+        p = src.permute(0, 3, 1, 2).float()
+        for i in range(3):
+            p = F.max_pool2d(p, 5, 1, 2)
+            assert torch.equal(xs[..., 40 + 24 * i:64 + 24 * i].float(), p.permute(0, 2, 3, 1)), (hh, ww, i)
     up = torch.zeros((2, 40, 40, 32), dtype=torch.float16, device="cuda")
     ctx.check(L.rva_upsample2x_nhwc_f16(ctx.handle, C.c_void_p(out.data_ptr()), 32, C.c_void_p(up.data_ptr()), 32, 2, 20, 20, 32, s))
     assert torch.equal(up, out.repeat_interleave(2, 1).repeat_interleave(2, 2))
