@@ -1300,20 +1300,25 @@ hipError_t launch_big(BigArgs &a, hipStream_t s)
 // Same ring / counted-vmcnt / raw-barrier structure as k_conv3_big, but a K-step is (tap, 64 channels): every staged
 // row is one full 128-byte line of a pixel (or of a weight row), a 1 KiB piece is 8 rows, and the bank-conflict-free
 // image is the XOR swizzle  physical chunk = chunk ^ (row & 7)  (applied on the per-lane source address; for
-// ds_read_b128 fragment reads the lane's xor term is the constant lane & 7).  Every wave owns BM/64 activation pieces
+// ds_read_b128 fragment reads the lane's xor term is the constant lane & 7).  BK = 32 (layers with Cin = 32 / 96)
+// uses 64-byte rows with the swz32 rotation instead, 16 rows per piece.  Every wave owns BM/64 activation pieces
 // and BN/64 weight pieces per step, so the vmcnt count is a compile-time constant.  Taps that fall outside the image
 // read a clamped address and are zeroed per lane in the B fragment (9-bit mask per pixel).  Needs Cin % 64 == 0.
-template <int BM, int BN, int WGM, int WGN, int NSLOT, int KS>
+template <int BM, int BN, int WGM, int WGN, int NSLOT, int KS, int BK>
 __global__ void __launch_bounds__(512)
-    __attribute__((amdgpu_waves_per_eu(NSLOT * (BM + BN) * 128 <= 80 * 1024 ? 4 : 2))) k_conv_gbig(ConvArgs a)
+    __attribute__((amdgpu_waves_per_eu(NSLOT * (BM + BN) * BK * 2 <= 80 * 1024 ? 4 : 2))) k_conv_gbig(ConvArgs a)
 {
     static_assert(WGM * WGN == 8, "eight waves");
+    static_assert(BK == 32 || BK == 64, "K-step of 32 or 64 channels");
     constexpr int TM = BM / WGM, TN = BN / WGN, FM = TM / 16, FN = TN / 16;
-    constexpr int NA = BM / 64, NW = BN / 64, NPW = NA + NW;      // pieces per wave per step
-    constexpr int SLOTH = (BM + BN) * 64;                          // halfs per ring slot
+    constexpr int RPP = 512 / BK;                                  // rows per 1 KiB piece (8 rows of 128 B / 16 of 64 B)
+    constexpr int LPR = BK / 8;                                    // lanes (16-byte chunks) per row
+    constexpr int APIECES = BM / RPP, WPIECES = BN / RPP;
+    constexpr int NA = (APIECES + 7) / 8, NW = (WPIECES + 7) / 8;  // pieces per wave per step (upper bounds)
+    constexpr int SLOTH = (BM + BN) * BK;                          // halfs per ring slot
     constexpr int TAPS = KS * KS, PAD = KS / 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __half *ring = (__half *)smem;                                 // [NSLOT][BM + BN][64]
+    __half *ring = (__half *)smem;                                 // [NSLOT][BM + BN][BK]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1321,17 +1326,19 @@ __global__ void __launch_bounds__(512)
     const int n_tile = blockIdx.x % a.n_tiles, m_tile = blockIdx.x / a.n_tiles;
     const int P0 = m_tile * BM, n0 = n_tile * BN;
     const int HoWo = a.Ho * a.Wo;
-    const int cpt = a.Cin >> 6;
+    const int cpt = a.Cin / BK;
     const int nsteps = TAPS * cpt;
     const int wrow = TAPS * a.Cin;
 
-    // per-lane constants of this wave's pieces (piece index = wv + 8k: k < NA activations, then weights)
-    const int lrow = lane >> 3, c8 = ((lane & 7) ^ lrow) * 8;      // source chunk of this lane (swizzle inverse)
+    // per-lane constants of this wave's pieces (piece index = wv + 8k within the activation / weight region)
+    const int lrow = lane / LPR, lp = lane % LPR;
+    // source chunk of this lane = inverse of the LDS swizzle (BK 64: chunk ^ (row & 7); BK 32: swz32's rotation)
+    const int c8 = (BK == 64 ? (lp ^ lrow) : ((lp - 2 * (lrow >> 2)) & 3)) * 8;
     int apix[NA], ayx[NA];      // flat input pixel of tap (0,0) and packed (iy0 + 2048) << 16 | (ix0 + 2048)
 #pragma unroll
     for (int k = 0; k < NA; ++k) {
-        const int m = P0 + (wv + 8 * k) * 8 + lrow;
-        if (m < a.M) {
+        const int m = P0 + (wv + 8 * k) * RPP + lrow;
+        if (wv + 8 * k < APIECES && m < a.M) {
             const int b = m / HoWo, rem = m - b * HoWo, oy = rem / a.Wo, ox = rem - oy * a.Wo;
             const int iy0 = oy * a.stride - PAD, ix0 = ox * a.stride - PAD;
             apix[k] = (b * a.H + iy0) * a.W + ix0;
@@ -1343,7 +1350,8 @@ __global__ void __launch_bounds__(512)
     }
     int woff[NW];
 #pragma unroll
-    for (int k = 0; k < NW; ++k) woff[k] = min(n0 + (wv + 8 * k) * 8 + lrow, a.CoutPad - 1) * wrow + c8;
+    for (int k = 0; k < NW; ++k) woff[k] = min(n0 + (wv + 8 * k) * RPP + lrow, a.CoutPad - 1) * wrow + c8;
+    const int my_pieces = max(0, (APIECES - wv + 7) / 8) + max(0, (WPIECES - wv + 7) / 8);
 
     auto issue = [&](int s) {
         const int tap = s / cpt, cc = s - tap * cpt;
@@ -1351,16 +1359,20 @@ __global__ void __launch_bounds__(512)
         __half *slot = ring + (size_t)(s % NSLOT) * SLOTH;
 #pragma unroll
         for (int k = 0; k < NA; ++k) {
-            const int iy = (ayx[k] >> 16) - 2048 + dy, ix = (ayx[k] & 0xffff) - 2048 + dx;
-            const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            const int q = ok ? apix[k] + dy * a.W + dx : 0;
-            const __half *src = a.in + (size_t)q * a.ldi + (cc << 6) + c8;
-            __builtin_amdgcn_global_load_lds((glb_vptr)src, (lds_vptr)(slot + (wv + 8 * k) * 512), 16, 0, 0);
+            if (wv + 8 * k < APIECES) {
+                const int iy = (ayx[k] >> 16) - 2048 + dy, ix = (ayx[k] & 0xffff) - 2048 + dx;
+                const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                const int q = ok ? apix[k] + dy * a.W + dx : 0;
+                const __half *src = a.in + (size_t)q * a.ldi + cc * BK + c8;
+                __builtin_amdgcn_global_load_lds((glb_vptr)src, (lds_vptr)(slot + (wv + 8 * k) * 512), 16, 0, 0);
+            }
         }
 #pragma unroll
         for (int k = 0; k < NW; ++k) {
-            const __half *src = a.w + (size_t)(woff[k] + tap * a.Cin + (cc << 6));
-            __builtin_amdgcn_global_load_lds((glb_vptr)src, (lds_vptr)(slot + BM * 64 + (wv + 8 * k) * 512), 16, 0, 0);
+            if (wv + 8 * k < WPIECES) {
+                const __half *src = a.w + (size_t)(woff[k] + tap * a.Cin + cc * BK);
+                __builtin_amdgcn_global_load_lds((glb_vptr)src, (lds_vptr)(slot + BM * BK + (wv + 8 * k) * 512), 16, 0, 0);
+            }
         }
     };
 
@@ -1396,9 +1408,9 @@ __global__ void __launch_bounds__(512)
 #pragma unroll
     for (int t = 0; t < NSLOT - 1; ++t)
         if (t < nsteps) issue(t);
-    const int xr = lane & 7;                                       // (row & 7) of every fragment row this lane reads
+    const int xr = lane & 7;                                       // BK 64: (row & 7) of every fragment row this lane reads
     for (int s = 0; s < nsteps; ++s) {
-        if (NSLOT == 3 && s + 1 < nsteps) wait_vm<NPW>(); else wait_vm<0>();
+        wait_vm_n(NSLOT == 3 && s + 1 < nsteps ? my_pieces : 0);
         __builtin_amdgcn_s_barrier();
         const int sn = s + NSLOT - 1;
         const bool more = sn < nsteps;
@@ -1406,20 +1418,21 @@ __global__ void __launch_bounds__(512)
         if (more && early) issue(sn);
         const int tap = s / cpt;
         const __half *ab = ring + (size_t)(s % NSLOT) * SLOTH;
-        const __half *wb = ab + BM * 64;
+        const __half *wb = ab + BM * BK;
         const int arow = wm * TM + (lane & 15), wr = wn * TN + (lane & 15);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int pc = ((ks * 4 + (lane >> 4)) ^ xr) * 8;
+        for (int ks = 0; ks < BK / 32; ++ks) {
             h8 bf[FM];
 #pragma unroll
             for (int j = 0; j < FM; ++j) {
-                bf[j] = *reinterpret_cast<const h8 *>(ab + (arow + 16 * j) * 64 + pc);
+                const int r = arow + 16 * j;
+                bf[j] = *reinterpret_cast<const h8 *>(ab + (BK == 64 ? r * 64 + ((ks * 4 + (lane >> 4)) ^ xr) * 8 : swz32(r, lane >> 4)));
                 if (KS == 3 && !((vm[j] >> tap) & 1)) bf[j] = hz;
             }
 #pragma unroll
             for (int i = 0; i < FN; ++i) {
-                const h8 af = *reinterpret_cast<const h8 *>(wb + (wr + 16 * i) * 64 + pc);
+                const int r = wr + 16 * i;
+                const h8 af = *reinterpret_cast<const h8 *>(wb + (BK == 64 ? r * 64 + ((ks * 4 + (lane >> 4)) ^ xr) * 8 : swz32(r, lane >> 4)));
 #pragma unroll
                 for (int j = 0; j < FM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[j], acc[i][j], 0, 0, 0);
             }
@@ -1470,34 +1483,34 @@ __global__ void __launch_bounds__(512)
     }
 }
 
-template <int BM, int BN, int WGM, int WGN, int NSLOT, int KS>
+template <int BM, int BN, int WGM, int WGN, int NSLOT, int KS, int BK>
 hipError_t launch_gbig1(ConvArgs &a, hipStream_t s)
 {
-    constexpr size_t ring = (size_t)NSLOT * (BM + BN) * 128;
+    constexpr size_t ring = (size_t)NSLOT * (BM + BN) * BK * 2;
     constexpr size_t st = (size_t)BM * (BN + 8) * 2;
     constexpr size_t smem = ring > st ? ring : st;
     static_assert(smem <= 160 * 1024, "LDS budget");
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_conv_gbig<BM, BN, WGM, WGN, NSLOT, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipError_t e = hipFuncSetAttribute((const void *)k_conv_gbig<BM, BN, WGM, WGN, NSLOT, KS, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
         attr = true;
     }
     a.n_tiles = rva_ceil_div(a.Cout, BN);
-    k_conv_gbig<BM, BN, WGM, WGN, NSLOT, KS><<<rva_ceil_div(a.M, BM) * a.n_tiles, 512, smem, s>>>(a);
+    k_conv_gbig<BM, BN, WGM, WGN, NSLOT, KS, BK><<<rva_ceil_div(a.M, BM) * a.n_tiles, 512, smem, s>>>(a);
     return hipGetLastError();
 }
 
-template <int BM, int BN, int WGM, int WGN, int NSLOT>
+template <int BM, int BN, int WGM, int WGN, int NSLOT, int BK = 64>
 hipError_t launch_gbig(ConvArgs &a, int ksize, hipStream_t s)
 {
-    if (a.Cin % 64 || a.H > 2000 || a.W > 2000) return hipErrorInvalidValue;
-    return ksize == 1 ? launch_gbig1<BM, BN, WGM, WGN, NSLOT, 1>(a, s) : launch_gbig1<BM, BN, WGM, WGN, NSLOT, 3>(a, s);
+    if (a.Cin % BK || a.H > 2000 || a.W > 2000) return hipErrorInvalidValue;
+    return ksize == 1 ? launch_gbig1<BM, BN, WGM, WGN, NSLOT, 1, BK>(a, s) : launch_gbig1<BM, BN, WGM, WGN, NSLOT, 3, BK>(a, s);
 }
 
 }  // namespace
 
-#define RVA_CONV_VARIANTS 39
+#define RVA_CONV_VARIANTS 42
 
 extern "C" {
 #ifdef RVA_ROW_STAMPS
@@ -1515,6 +1528,7 @@ int rva_dbg_read_stamps(unsigned long long *host) { return (int)hipMemcpyFromSym
 //          two or three blocks per CU; the extra tile heights exist so that the tile count can fit whole rounds of the 256 CUs
 //   33..38 large-tile LDS-DMA gather kernel with 64-channel K-steps (1x1; 3x3 stride 1 or 2; Cin % 64 == 0):
 //          <256,128> <128,128> <256,64> <128,64> 3-slot, <128,128> <256,64> <192,128> 2-slot
+//   40..42 the same with 32-channel K-steps (Cin % 32 == 0): <256,64> 3-slot, <128,64> 3-slot, <256,64> 2-slot
 int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *weights, const float *bias, void *out,
                           int ldo, const void *residual, int ldr, int batch, int H, int W, int Cin, int Cout, int ksize,
                           int stride, int act, int variant, rva_stream_t stream_);
@@ -1580,7 +1594,11 @@ int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *wei
         case 36: ev = launch_gbig<128, 64, 2, 4, 3>(a, ksize, s); break;     // 72 KB: two blocks per CU
         case 37: ev = launch_gbig<128, 128, 2, 4, 2>(a, ksize, s); break;    // 64 KB: two blocks per CU
         case 38: ev = launch_gbig<256, 64, 4, 2, 2>(a, ksize, s); break;     // 80 KB: two blocks per CU
-        default: ev = launch_gbig<192, 128, 4, 2, 2>(a, ksize, s); break;    // 80 KB: two blocks per CU
+        case 39: ev = launch_gbig<192, 128, 4, 2, 2>(a, ksize, s); break;    // 80 KB: two blocks per CU
+        // 32-channel K-steps (64-byte rows, swz32): the layers with Cin = 32 / 96
+        case 40: ev = launch_gbig<256, 64, 4, 2, 3, 32>(a, ksize, s); break; // 60 KB: two blocks per CU
+        case 41: ev = launch_gbig<128, 64, 2, 4, 3, 32>(a, ksize, s); break; // 36 KB: four blocks per CU
+        default: ev = launch_gbig<256, 64, 4, 2, 2, 32>(a, ksize, s); break; // 40 KB: three blocks per CU
         }
         if (ev == hipSuccess) return RVA_OK;
         (void)hipGetLastError();

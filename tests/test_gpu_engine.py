@@ -74,7 +74,9 @@ def test_conv_primitive_matches_fp32_reference(shape):
                                    # LDS-DMA kernels: odd sizes with stride 2, Cout that is no multiple of the channel tile,
                                    # a tensor smaller than one tile, tiles that straddle image borders, many tiles
                                    (3, 17, 23, 64, 80, 3, 2), (2, 13, 11, 128, 80, 1, 1), (1, 5, 5, 64, 64, 3, 1),
-                                   (5, 12, 10, 64, 192, 3, 1), (4, 80, 80, 64, 64, 3, 1), (2, 40, 40, 192, 128, 1, 1)])
+                                   (5, 12, 10, 64, 192, 3, 1), (4, 80, 80, 64, 64, 3, 1), (2, 40, 40, 192, 128, 1, 1),
+                                   # 32-channel-step LDS-DMA gather: the Cin = 32 / 96 layers
+                                   (2, 21, 18, 32, 64, 3, 2), (2, 16, 16, 96, 64, 1, 1), (1, 160, 160, 32, 64, 3, 2)])
 def test_every_conv_variant_agrees(shape):
     """All kernel variants the autotuner may pick (gather / resident / row-reuse, every tile) give the same layer."""
     B, H, W, Cin, Cout, k, stride = shape
@@ -105,7 +107,9 @@ def test_every_conv_variant_agrees(shape):
     if k == 3 and stride == 1:
         assert any(9 <= v <= 20 for v in ran), ran       # the row-reuse kernel took part
         if Cin % 32 == 0:
-            assert any(v >= 21 for v in ran), ran      # the large-tile LDS-DMA kernel took part
+            assert any(21 <= v <= 32 for v in ran), ran      # the large-tile LDS-DMA kernel took part
+    if Cin % 32 == 0:
+        assert any(v >= 40 for v in ran), ran          # the 32-channel-step LDS-DMA gather kernel took part
 
 
 def test_pool_upsample_head_primitives():
