@@ -747,15 +747,27 @@ __global__ void __launch_bounds__(256) k_stem(StemArgs a, const __half *__restri
     // v_mfma_f32_16x16x32_f16 step per 16x16 output block (weights = A operand, loaded once per block;
     // pixels = B operand).  A VALU formulation needs 864 FMAs per pixel and saturated the scalar unit.
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __half *tile = (__half *)smem;                                              // [3][17][66]
-    __half *col = (__half *)(smem + ((3 * 17 * 66 * 2 + 15) & ~15));            // [256][LDSROW] im2col rows / output stage
+    constexpr int RS = 88;                                                      // halfs per patch row: 80 used (x = 64*tx-8 ...) + 8 pad
+    __half *tile = (__half *)smem;                                              // [3][17][RS]
+    __half *col = (__half *)(smem + 3 * 17 * RS * 2);                           // [256][LDSROW] im2col rows / output stage
     __half *wl = col + 256 * (a.Cout + 8 > LDSROW ? a.Cout + 8 : LDSROW);       // [64][LDSROW] weights (fp16, K padded)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tiles_x = (a.Wo + 31) >> 5, tiles_y = (a.Ho + 7) >> 3;
     const int tiles_img = tiles_x * tiles_y, total = tiles_img * a.B;
-    {   // packed fp16 weights [64][32]: one 16-byte load per thread, once per block
+    {   // packed fp16 weights [64][32] (API column order: k = 2j + kx for kx in {0,1}, 18 + j for kx = 2, j = c*3 + ky):
+        // one 16-byte load per thread, once per block, scattered into the kernel's own K order
+        //   k' = 2j + (kx - 1) for kx in {1,2}  (one aligned dword of the patch row),  k' = 18 + j for kx = 0
         const u4 wv4 = *reinterpret_cast<const u4 *>(gw + tid * 8);
-        *reinterpret_cast<u4 *>(wl + (size_t)(tid >> 2) * LDSROW + (tid & 3) * 8) = wv4;
+        const unsigned short *wh = reinterpret_cast<const unsigned short *>(&wv4);
+        unsigned short *wrow_l = reinterpret_cast<unsigned short *>(wl) + (size_t)(tid >> 2) * LDSROW;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = (tid & 3) * 8 + e;
+            int kn = k;                                           // k >= 27: zero padding stays in place
+            if (k < 18) { const int j = k >> 1; kn = (k & 1) ? 2 * j : 18 + j; }        // kx = 1 -> 2j ; kx = 0 -> 18 + j
+            else if (k < 27) kn = 2 * (k - 18) + 1;                                      // kx = 2 -> 2j + 1
+            wrow_l[kn] = wh[e];
+        }
     }
     const int nblk = (a.Cout + 15) >> 4;                   // 16-channel blocks (<= 4)
     float bv[4][4];
@@ -766,52 +778,57 @@ __global__ void __launch_bounds__(256) k_stem(StemArgs a, const __half *__restri
             const int co = 16 * i + (lane >> 4) * 4 + u;
             bv[i][u] = co < a.Cout ? gb[co] : 0.f;
         }
-    constexpr int NR = 13;                                 // ceil(51 patch rows / 4 waves)
-    unsigned short v0[NR], v1[NR];
-    const bool has_x1 = lane == 0;                         // lane 0 also fetches column 64
-    auto prefetch = [&](int t) {                           // lanes walk along x: no div/mod per element
+    // patch of a tile: 3 planes x 17 rows x 80 halfs starting at x = 64*tx - 8 (so that every row is a run of ten aligned
+    // 16-byte chunks; W % 8 == 0).  510 chunks per tile = two 16-byte loads per thread -- the earlier form issued 26
+    // two-byte loads per thread and spent a third of the tile time in the issue of those loads (tools/stem_stamps.py).
+    u4 pv[2];
+    auto prefetch = [&](int t) {
         const int bb = t / tiles_img, r2 = t - bb * tiles_img, tyy = r2 / tiles_x, txx = r2 - tyy * tiles_x;
-        const int ix0 = txx * 64 - 1, iy0 = tyy * 16 - 1;
+        const int x00 = txx * 64 - 8, iy0 = tyy * 16 - 1;
 #pragma unroll
-        for (int k = 0; k < NR; ++k) {
-            const int row = wv + 4 * k;                    // 0..50
+        for (int k = 0; k < 2; ++k) {
+            const int q = tid + 256 * k;
+            const int row = q / 10, cx = q - row * 10;
             const int c = row / 17, r = row - c * 17;
-            const int iy = iy0 + r, ix = ix0 + lane;
-            v0[k] = 0; v1[k] = 0;
-            if (!(a.dbg & 1) && row < 51 && (unsigned)iy < (unsigned)a.H) {
-                const unsigned short *src = reinterpret_cast<const unsigned short *>(a.in) + ((size_t)(bb * 3 + c) * a.H + iy) * a.W;
-                if ((unsigned)ix < (unsigned)a.W) v0[k] = src[ix];
-                if (has_x1 && (unsigned)(ix0 + 64) < (unsigned)a.W) v1[k] = src[ix0 + 64];
-            }
+            const int iy = iy0 + r, x0 = x00 + cx * 8;
+            pv[k] = u4{0u, 0u, 0u, 0u};
+            if (!(a.dbg & 1) && q < 510 && (unsigned)iy < (unsigned)a.H && (unsigned)x0 < (unsigned)a.W)
+                pv[k] = *reinterpret_cast<const u4 *>(a.in + ((size_t)(bb * 3 + c) * a.H + iy) * a.W + x0);
         }
     };
+#ifdef RVA_ROW_STAMPS
+    const int st_stride = gridDim.x / 8;
+    const bool st_on = tid == 0 && st_stride > 0 && blockIdx.x % st_stride == 0 && blockIdx.x / st_stride < 8;
+    const int st_slot = st_on ? blockIdx.x / st_stride : 0;
+    int st_n = 0;
+#endif
     int t = blockIdx.x;
     if (t < total) prefetch(t);
     for (; t < total; t += gridDim.x) {
+        STAMP(0);
         const int b = t / tiles_img, r2 = t - b * tiles_img, ty = r2 / tiles_x, tx = r2 - ty * tiles_x;
         const int ox0 = tx * 32, oy0 = ty * 8;
 #pragma unroll
-        for (int k = 0; k < NR; ++k) {
-            const int row = wv + 4 * k;
-            if (row < 51) {
-                unsigned short *dst = reinterpret_cast<unsigned short *>(tile) + row * 66;
-                dst[lane] = v0[k];
-                if (has_x1) dst[64] = v1[k];
-            }
+        for (int k = 0; k < 2; ++k) {
+            const int q = tid + 256 * k;
+            const int row = q / 10, cx = q - row * 10;
+            if (q < 510) *reinterpret_cast<u4 *>(tile + row * RS + cx * 8) = pv[k];
         }
         __syncthreads();
+        STAMP(1);
         if (t + (int)gridDim.x < total) prefetch(t + gridDim.x);   // next tile's patch flies under this tile's work
-        {   // im2col row of this thread's pixel.  K order (shared with the host-packed weights):
-            //   k = 2*j + kx for kx in {0,1}  (j = c*3 + ky): the two halfs are one aligned dword of the patch row,
-            //   k = 18 + j   for kx = 2, k = 27..31 zero.
+        STAMP(2);
+        {   // im2col row of this thread's pixel.  K order (the weights were scattered into it above):
+            //   k' = 2*j + (kx - 1) for kx in {1,2}  (j = c*3 + ky): halfs 2*lx+8, 2*lx+9 of the patch row = one aligned dword,
+            //   k' = 18 + j for kx = 0 (half 2*lx+7), k' = 27..31 zero.
             const int lx = tid & 31, ly = tid >> 5;
             uint32_t d[16];
             unsigned short sgl[9];
 #pragma unroll
             for (int j = 0; j < 9; ++j) {
-                const __half *p = tile + ((j / 3) * 17 + ly * 2 + (j % 3)) * 66 + lx * 2;
-                d[j] = *reinterpret_cast<const uint32_t *>(p);                 // kx = 0, 1
-                sgl[j] = *reinterpret_cast<const unsigned short *>(p + 2);     // kx = 2
+                const __half *p = tile + ((j / 3) * 17 + ly * 2 + (j % 3)) * RS + lx * 2 + 8;
+                d[j] = *reinterpret_cast<const uint32_t *>(p);                 // kx = 1, 2
+                sgl[j] = *reinterpret_cast<const unsigned short *>(p - 1);     // kx = 0
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) d[9 + j] = (uint32_t)sgl[2 * j] | ((uint32_t)sgl[2 * j + 1] << 16);
@@ -822,6 +839,7 @@ __global__ void __launch_bounds__(256) k_stem(StemArgs a, const __half *__restri
                 *reinterpret_cast<u4 *>(col + (size_t)tid * LDSROW + q * 8) = u4{d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]};
         }
         __syncthreads();
+        STAMP(3);
         f4 acc[4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -838,6 +856,7 @@ __global__ void __launch_bounds__(256) k_stem(StemArgs a, const __half *__restri
                 for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[j], acc[i][j], 0, 0, 0);
             }
         }
+        STAMP(4);
         __syncthreads();                                    // im2col rows are dead: reuse them as the output stage
         const int srow = a.Cout + 8;
         __half *stage = col;
@@ -858,6 +877,7 @@ __global__ void __launch_bounds__(256) k_stem(StemArgs a, const __half *__restri
             }
         }
         __syncthreads();
+        STAMP(5);
         const int cpr = a.Cout >> 3;
         for (int q = tid; q < 256 * cpr; q += 256) {
             const int px = q / cpr, pc = q - px * cpr;
@@ -866,6 +886,7 @@ __global__ void __launch_bounds__(256) k_stem(StemArgs a, const __half *__restri
                 *reinterpret_cast<uint4 *>(a.out + ((size_t)(b * a.Ho + oy) * a.Wo + ox) * a.ldo + pc * 8) =
                     *reinterpret_cast<const uint4 *>(stage + (size_t)px * srow + pc * 8);
         }
+        STAMP(6);
         // the next iteration's first barrier (after the tile fill) also orders these stage reads before the
         // next im2col writes; the tile buffer itself is not touched by the output copy
     }
@@ -1746,7 +1767,8 @@ int rva_stem_conv_f16(rva_ctx *ctx, const void *in_planar, const void *weights, 
     const int total_tiles = rva_ceil_div(a.Wo, 32) * rva_ceil_div(a.Ho, 8) * batch;
     int grid = 256 * 4;                                     // persistent: ~4 blocks per CU (LDS-limited)
     if (grid > total_tiles) grid = total_tiles;
-    k_stem<<<grid, 256, (size_t)((3 * 17 * 66 * 2 + 15) & ~15) + (size_t)(256 * (Cout + 8 > LDSROW ? Cout + 8 : LDSROW) + 64 * LDSROW) * 2, (hipStream_t)stream_>>>(a, (const __half *)weights, bias);
+    if (W % 8 || ((uintptr_t)in_planar & 15)) return rva_fail(ctx, RVA_ERR_ARG, "rva_stem_conv_f16: W %% 8 == 0 and a 16-byte aligned input are required");
+    k_stem<<<grid, 256, (size_t)(3 * 17 * 88 * 2) + (size_t)(256 * (Cout + 8 > LDSROW ? Cout + 8 : LDSROW) + 64 * LDSROW) * 2, (hipStream_t)stream_>>>(a, (const __half *)weights, bias);
     RVA_HIP(ctx, hipGetLastError());
     return RVA_OK;
 }
