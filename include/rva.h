@@ -253,6 +253,13 @@ int rva_conv2d_nhwc_f16(rva_ctx *ctx, const void *in, int ldi, const void *weigh
 int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *weights, const float *bias,
                           void *out, int ldo, const void *residual, int ldr, int batch, int H, int W, int Cin,
                           int Cout, int ksize, int stride, int act, int variant, rva_stream_t stream);
+/* 1x1 convolution whose input is torch.cat([nearest-2x-upsample(low), skip], channel) -- the FPN pattern -- without
+ * materialising either the upsampled tensor or the concatenation: low is [batch, H/2, W/2, c_low], skip is
+ * [batch, H, W, c_skip] (row strides ld_low / ld_skip), weights [rva_conv_cout_pad(Cout)][1][c_low + c_skip].
+ * c_low % 64 == c_skip % 64 == 0, H and W even.  variant: 0 or one of the LDS-DMA gather variants 33..39. */
+int rva_conv1x1_upcat_f16(rva_ctx *ctx, const void *low, int ld_low, int c_low, const void *skip, int ld_skip,
+                          int c_skip, const void *weights, const float *bias, void *out, int ldo, int batch,
+                          int H, int W, int Cout, int act, int variant, rva_stream_t stream);
 int rva_stem_conv_f16(rva_ctx *ctx, const void *in_planar, const void *weights, const float *bias,
                       void *out, int ldo, int batch, int H, int W, int Cout, rva_stream_t stream);
 /* SPPF's three chained 5x5/1 max pools in one launch: out1 = pool5(in), out2 = pool5(out1) = pool9(in),

@@ -47,6 +47,8 @@ struct ConvArgs {
     __half *out; int ldo;
     const __half *res; int ldr;
     int CoutPad;
+    const __half *in2; int ldi2, c_split;   // k_conv_gbig<..., UP>: `in` = low-res tensor (nearest 2x upsampled on the fly,
+                                            // channels [0, c_split)), `in2` = full-res tensor (channels [c_split, Cin))
     int H, W, Cin, CinPad, Ho, Wo, Cout, stride, M, act, n_tiles, m_tiles;   // CinPad = Cin rounded up to 32 (weight rows are zero-padded)
 };
 
@@ -1325,12 +1327,13 @@ hipError_t launch_big(BigArgs &a, hipStream_t s)
 // uses 64-byte rows with the swz32 rotation instead, 16 rows per piece.  Every wave owns BM/64 activation pieces
 // and BN/64 weight pieces per step, so the vmcnt count is a compile-time constant.  Taps that fall outside the image
 // read a clamped address and are zeroed per lane in the B fragment (9-bit mask per pixel).  Needs Cin % 64 == 0.
-template <int BM, int BN, int WGM, int WGN, int NSLOT, int KS, int BK>
+template <int BM, int BN, int WGM, int WGN, int NSLOT, int KS, int BK, bool UP = false>
 __global__ void __launch_bounds__(512)
     __attribute__((amdgpu_waves_per_eu(NSLOT * (BM + BN) * BK * 2 <= 80 * 1024 ? 4 : 2))) k_conv_gbig(ConvArgs a)
 {
     static_assert(WGM * WGN == 8, "eight waves");
     static_assert(BK == 32 || BK == 64, "K-step of 32 or 64 channels");
+    static_assert(!UP || (KS == 1 && BK == 64), "the upsample + concat source form exists for 1x1 convolutions");
     constexpr int TM = BM / WGM, TN = BN / WGN, FM = TM / 16, FN = TN / 16;
     constexpr int RPP = 512 / BK;                                  // rows per 1 KiB piece (8 rows of 128 B / 16 of 64 B)
     constexpr int LPR = BK / 8;                                    // lanes (16-byte chunks) per row
@@ -1356,14 +1359,17 @@ __global__ void __launch_bounds__(512)
     // source chunk of this lane = inverse of the LDS swizzle (BK 64: chunk ^ (row & 7); BK 32: swz32's rotation)
     const int c8 = (BK == 64 ? (lp ^ lrow) : ((lp - 2 * (lrow >> 2)) & 3)) * 8;
     int apix[NA], ayx[NA];      // flat input pixel of tap (0,0) and packed (iy0 + 2048) << 16 | (ix0 + 2048)
+    int apix2[UP ? NA : 1];     // UP: the pixel of the low-res source that nearest-2x upsampling maps onto this one
 #pragma unroll
     for (int k = 0; k < NA; ++k) {
         const int m = P0 + (wv + 8 * k) * RPP + lrow;
+        if (UP) apix2[k] = 0;
         if (wv + 8 * k < APIECES && m < a.M) {
             const int b = m / HoWo, rem = m - b * HoWo, oy = rem / a.Wo, ox = rem - oy * a.Wo;
             const int iy0 = oy * a.stride - PAD, ix0 = ox * a.stride - PAD;
             apix[k] = (b * a.H + iy0) * a.W + ix0;
             ayx[k] = ((iy0 + 2048) << 16) | (ix0 + 2048);
+            if (UP) apix2[k] = (b * (a.H >> 1) + (oy >> 1)) * (a.W >> 1) + (ox >> 1);
         } else {
             apix[k] = 0;
             ayx[k] = 0;                                            // iy0 = ix0 = -2048: never valid
@@ -1385,6 +1391,11 @@ __global__ void __launch_bounds__(512)
                 const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
                 const int q = ok ? apix[k] + dy * a.W + dx : 0;
                 const __half *src = a.in + (size_t)q * a.ldi + cc * BK + c8;
+                if (UP) {   // torch.cat([upsample2x(low), skip], channel): each 64-channel chunk comes from one of the two
+                    const int ch = cc * BK;
+                    src = ch < a.c_split ? a.in + (size_t)apix2[k] * a.ldi + ch + c8
+                                         : a.in2 + (size_t)q * a.ldi2 + (ch - a.c_split) + c8;
+                }
                 __builtin_amdgcn_global_load_lds((glb_vptr)src, (lds_vptr)(slot + (wv + 8 * k) * 512), 16, 0, 0);
             }
         }
@@ -1504,7 +1515,7 @@ __global__ void __launch_bounds__(512)
     }
 }
 
-template <int BM, int BN, int WGM, int WGN, int NSLOT, int KS, int BK>
+template <int BM, int BN, int WGM, int WGN, int NSLOT, int KS, int BK, bool UP = false>
 hipError_t launch_gbig1(ConvArgs &a, hipStream_t s)
 {
     constexpr size_t ring = (size_t)NSLOT * (BM + BN) * BK * 2;
@@ -1513,12 +1524,12 @@ hipError_t launch_gbig1(ConvArgs &a, hipStream_t s)
     static_assert(smem <= 160 * 1024, "LDS budget");
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_conv_gbig<BM, BN, WGM, WGN, NSLOT, KS, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipError_t e = hipFuncSetAttribute((const void *)k_conv_gbig<BM, BN, WGM, WGN, NSLOT, KS, BK, UP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
         attr = true;
     }
     a.n_tiles = rva_ceil_div(a.Cout, BN);
-    k_conv_gbig<BM, BN, WGM, WGN, NSLOT, KS, BK><<<rva_ceil_div(a.M, BM) * a.n_tiles, 512, smem, s>>>(a);
+    k_conv_gbig<BM, BN, WGM, WGN, NSLOT, KS, BK, UP><<<rva_ceil_div(a.M, BM) * a.n_tiles, 512, smem, s>>>(a);
     return hipGetLastError();
 }
 
@@ -1750,6 +1761,37 @@ int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *wei
     else e = small ? RVA_CONV(64, 32) : RVA_CONV(64, 64);
 #undef RVA_CONV
     if (e != hipSuccess) return rva_fail(ctx, RVA_ERR_HIP, "conv launch failed: %s", hipGetErrorString(e));
+    return RVA_OK;
+}
+
+int rva_conv1x1_upcat_f16(rva_ctx *ctx, const void *low, int ld_low, int c_low, const void *skip, int ld_skip, int c_skip,
+                          const void *weights, const float *bias, void *out, int ldo, int batch, int H, int W, int Cout,
+                          int act, int variant, rva_stream_t stream_)
+{
+    if (!ctx) return RVA_ERR_ARG;
+    if (!low || !skip || !weights || !bias || !out || batch <= 0 || H <= 0 || W <= 0 || (H | W) & 1 || c_low <= 0 || c_skip <= 0 ||
+        c_low % 64 || c_skip % 64 || Cout % 8 || ld_low % 8 || ld_skip % 8 || ldo % 8 ||
+        ((uintptr_t)low | (uintptr_t)skip | (uintptr_t)out | (uintptr_t)weights) % 16 || H > 2000 || W > 2000)
+        return rva_fail(ctx, RVA_ERR_ARG, "rva_conv1x1_upcat_f16: unsupported shape/alignment (even H, W; channel counts %% 64; ld %% 8)");
+    ConvArgs a{};
+    a.in = (const __half *)low; a.ldi = ld_low; a.in2 = (const __half *)skip; a.ldi2 = ld_skip; a.c_split = c_low;
+    a.w = (const __half *)weights; a.bias = bias; a.out = (__half *)out; a.ldo = ldo; a.res = nullptr; a.ldr = 0;
+    a.H = H; a.W = W; a.Cin = c_low + c_skip; a.CinPad = a.Cin; a.Cout = Cout; a.stride = 1; a.act = act;
+    a.Ho = H; a.Wo = W; a.M = batch * H * W; a.CoutPad = rva_ceil_div(Cout, 64) * 64;
+    hipStream_t s = (hipStream_t)stream_;
+    hipError_t ev;
+    switch (variant) {
+    case 33: ev = launch_gbig1<256, 128, 4, 2, 3, 1, 64, true>(a, s); break;
+    case 34: ev = launch_gbig1<128, 128, 2, 4, 3, 1, 64, true>(a, s); break;
+    case 35: ev = launch_gbig1<256, 64, 4, 2, 3, 1, 64, true>(a, s); break;
+    case 36: ev = launch_gbig1<128, 64, 2, 4, 3, 1, 64, true>(a, s); break;
+    case 0:
+    case 37: ev = launch_gbig1<128, 128, 2, 4, 2, 1, 64, true>(a, s); break;
+    case 38: ev = launch_gbig1<256, 64, 4, 2, 2, 1, 64, true>(a, s); break;
+    case 39: ev = launch_gbig1<192, 128, 4, 2, 2, 1, 64, true>(a, s); break;
+    default: return rva_fail(ctx, RVA_ERR_ARG, "rva_conv1x1_upcat_f16: variant %d not applicable (0 or 33..39)", variant);
+    }
+    if (ev != hipSuccess) return rva_fail(ctx, RVA_ERR_HIP, "rva_conv1x1_upcat_f16: launch failed: %s", hipGetErrorString(ev));
     return RVA_OK;
 }
 

@@ -119,11 +119,36 @@ class FusedYoloV8:
         self._tunable.append((launch, state, f"{cin}->{cout} k{k}s{stride} {h}x{w}"))
         return (h - 1) // stride + 1 if k == 3 else h // stride, (w - 1) // stride + 1 if k == 3 else w // stride
 
-    def _c2f(self, mod: C2f, src: _View, dst: _View, h: int, w: int):
+    def _conv_upcat(self, mod, low: _View, skip: _View, dst: _View, h: int, w: int):
+        """1x1 convolution of cat([upsample2x(low), skip]) in one launch (rva_conv1x1_upcat_f16): neither the upsampled
+        tensor nor the concatenation exists in memory."""
+        conv = mod.conv if isinstance(mod, ConvBnAct) else mod
+        act = 1 if isinstance(mod, ConvBnAct) and mod.act else 0
+        wp, bp, cin, cout, k, stride = self._conv_params(conv)
+        assert k == 1 and stride == 1 and cin == low.ch + skip.ch and cout == dst.ch and cin % 32 == 0
+        B, L, ctx = self.B, self.L, self.ctx
+        state = {"variant": 0}
+
+        def launch(stream, variant):
+            if variant and not 33 <= variant <= 39:
+                return N.RVA_ERR_ARG
+            return L.rva_conv1x1_upcat_f16(ctx.handle, low.ptr, low.ld, low.ch, skip.ptr, skip.ld, skip.ch, _p(wp), _p(bp),
+                                           dst.ptr, dst.ld, B, h, w, cout, act, variant, stream)
+
+        def run(stream):
+            ctx.check(launch(stream, state["variant"]), "rva_conv1x1_upcat_f16")
+        self._steps.append(run)
+        self._tunable.append((launch, state, f"up{low.ch}+{skip.ch}->{cout} k1s1 {h}x{w}"))
+
+    def _c2f(self, mod: C2f, src, dst: _View, h: int, w: int):
+        """``src``: a view, or a pair (low, skip) standing for cat([upsample2x(low), skip])."""
         c, n = mod.c, len(mod.m)
         m = self.B * h * w
         cat = _View(self._buf(m, (2 + n) * c), 0, (2 + n) * c)
-        self._conv(mod.cv1, src, cat.sub(0, 2 * c), h, w)
+        if isinstance(src, tuple):
+            self._conv_upcat(mod.cv1, src[0], src[1], cat.sub(0, 2 * c), h, w)
+        else:
+            self._conv(mod.cv1, src, cat.sub(0, 2 * c), h, w)
         tmp = _View(self._buf(m, c), 0, c)
         for i, b in enumerate(mod.m):
             x = cat.sub((1 + i) * c, c)
@@ -205,11 +230,16 @@ class FusedYoloV8:
         t5b = _View(self._buf(B * h5 * w5, c5), 0, c5)
         self._c2f(net.b8, t5, t5b, h5, w5)
         self._sppf(net.b9, t5b, p5, h5, w5)
-        self._upsample(p5, cat12.sub(0, c5), h5, w5)
-        self._c2f(net.h12, cat12, n4, h4, w4)
-        self._upsample(n4, cat15.sub(0, c4), h4, w4)
+        fuse_up = c5 % 64 == 0 and c4 % 64 == 0 and c3 % 64 == 0 and h4 == 2 * h5 and w4 == 2 * w5 and h3 == 2 * h4 and w3 == 2 * w4
         n3 = _View(self._buf(B * h3 * w3, c3), 0, c3)
-        self._c2f(net.h15, cat15, n3, h3, w3)
+        if fuse_up:      # FPN top-down path: upsample + concat folded into the consuming 1x1 convolutions
+            self._c2f(net.h12, (p5, p4), n4, h4, w4)
+            self._c2f(net.h15, (n4, p3), n3, h3, w3)
+        else:
+            self._upsample(p5, cat12.sub(0, c5), h5, w5)
+            self._c2f(net.h12, cat12, n4, h4, w4)
+            self._upsample(n4, cat15.sub(0, c4), h4, w4)
+            self._c2f(net.h15, cat15, n3, h3, w3)
         self._conv(net.h16, n3, cat18.sub(0, c3), h3, w3)
         m4 = _View(self._buf(B * h4 * w4, c4), 0, c4)
         self._c2f(net.h18, cat18, m4, h4, w4)

@@ -151,3 +151,35 @@ def test_fused_plan_matches_torch_module(scale, batch):
     assert (got[:, 4:] - want[:, 4:]).abs().max() < 2e-2         # class probabilities
     # tighter in the mean: the plan is not systematically off
     assert (got[:, :4] - want[:, :4]).abs().mean() < 0.2
+
+
+@pytest.mark.parametrize("shape", [(2, 20, 20, 128, 64, 64), (1, 40, 24, 64, 128, 80), (3, 8, 10, 192, 64, 256)])
+def test_upcat_conv_matches_torch(shape):
+    """1x1 conv over cat([upsample2x(low), skip]) without materialising either: every applicable variant."""
+    B, H, W, c_low, c_skip, Cout = shape
+    g = torch.Generator().manual_seed(3)
+    low = (torch.randn((B, H // 2, W // 2, c_low + 16), generator=g) * 0.5).half().cuda()       # channel slices with a
+    skip = (torch.randn((B, H, W, 8 + c_skip), generator=g) * 0.5).half().cuda()                # stride, like the plan
+    Cin = c_low + c_skip
+    w = (torch.randn((Cout, Cin, 1, 1), generator=g) / Cin ** 0.5).half()
+    b = torch.randn((Cout,), generator=g) * 0.1
+    L, ctx = N.lib(), ops.context()
+    cpad = L.rva_conv_cout_pad(Cout)
+    wp = torch.zeros((cpad, 1, Cin), dtype=torch.float16); wp[:Cout, 0] = w[:, :, 0, 0]
+    bp = torch.zeros(cpad); bp[:Cout] = b
+    wp, bp = wp.cuda(), bp.cuda()
+    up = low[..., :c_low].repeat_interleave(2, 1).repeat_interleave(2, 2)
+    x = torch.cat([up, skip[..., 8:]], -1)
+    want = _conv_ref(x, w.cuda(), b.cuda(), 1, 1, 1, None)
+    ran = 0
+    for variant in [0] + list(range(33, 40)):
+        out = torch.zeros((B, H, W, Cout), dtype=torch.float16, device="cuda")
+        rc = L.rva_conv1x1_upcat_f16(ctx.handle, C.c_void_p(low.data_ptr()), c_low + 16, c_low, C.c_void_p(skip.data_ptr() + 16), 8 + c_skip,
+                                     c_skip, C.c_void_p(wp.data_ptr()), C.c_void_p(bp.data_ptr()), C.c_void_p(out.data_ptr()), Cout,
+                                     B, H, W, Cout, 1, variant, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        ctx.check(rc)
+        torch.cuda.synchronize()
+        err = (out.float() - want).abs().max().item()
+        assert err < 2e-2 + 2e-3 * want.abs().max().item(), (variant, err)
+        ran += 1
+    assert ran == 8

@@ -16,10 +16,16 @@ rows = []
 for d, n in seen.items():
     v, us = t[d]
     tot += us * n
-    cin, cout, k, st, h, w = map(int, re.match(r"(\d+)->(\d+) k(\d)s(\d) (\d+)x(\d+)", d).groups())
-    ho, wo = ((h - 1) // st + 1, (w - 1) // st + 1) if k == 3 else (h // st, w // st)
+    mu = re.match(r"up(\d+)\+(\d+)->(\d+) k1s1 (\d+)x(\d+)", d)
+    if mu:      # fused upsample + concat source: the low-res part is read at quarter size
+        cl, cs, cout, h, w = map(int, mu.groups())
+        cin, k, st, ho, wo = cl + cs, 1, 1, h, w
+        by = 2 * (B * (h // 2) * (w // 2) * cl + B * h * w * cs + B * h * w * cout)
+    else:
+        cin, cout, k, st, h, w = map(int, re.match(r"(\d+)->(\d+) k(\d)s(\d) (\d+)x(\d+)", d).groups())
+        ho, wo = ((h - 1) // st + 1, (w - 1) // st + 1) if k == 3 else (h // st, w // st)
+        by = 2 * (B * h * w * cin + B * ho * wo * cout)
     fl = 2 * B * ho * wo * cout * cin * k * k
-    by = 2 * (B * h * w * cin + B * ho * wo * cout)
     t_hbm, t_mfma = by / 6.0e6, fl / 2.5e9          # us at 6 TB/s achievable HBM, 2.5 PFLOP/s dense fp16
     roof = max(t_hbm, t_mfma)
     gap = (us - roof) * n
