@@ -274,6 +274,10 @@ int rva_upsample2x_nhwc_f16(rva_ctx *ctx, const void *in, int ldi, void *out, in
 int rva_yolo_head_f16(rva_ctx *ctx, const void *box_logits, int ldb, const void *cls_logits, int ldc,
                       void *out, int batch, int h, int w, int nc, int anchors_total, int anchor_offset,
                       float stride, rva_stream_t stream);
+/* The three pyramid levels (strides 8 / 16 / 32) in one launch; arrays of 3, anchor offsets follow from h*w. */
+int rva_yolo_head3_f16(rva_ctx *ctx, const void *const *box_logits, const int32_t *ldb, const void *const *cls_logits,
+                       const int32_t *ldc, void *out, int batch, const int32_t *h, const int32_t *w, int nc,
+                       int anchors_total, const float *strides, rva_stream_t stream);
 
 /* ----------------------------------------------------------------------------------------------
  * K5 motion gate -- replaces MotionFilter.should_process (utils/frame_filter.py:26-40)

@@ -993,12 +993,29 @@ struct HeadArgs {
     int B, h, w, nc, A, a0; float stride;
 };
 
+struct Head3Args { HeadArgs lv[3]; int blocks[3]; };     // blocks[l] = 256-anchor blocks of level l
+
+__device__ __forceinline__ void head_anchor(const HeadArgs &a, int i, int b);
+
 __global__ void __launch_bounds__(256) k_head(HeadArgs a)
 {
-    const int hw = a.h * a.w;
     const int i = blockIdx.x * 256 + threadIdx.x;
-    const int b = blockIdx.y;
-    if (i >= hw) return;
+    if (i < a.h * a.w) head_anchor(a, i, blockIdx.y);
+}
+
+// the three pyramid levels in one launch: the two small levels no longer run as separate, under-filled kernels
+__global__ void __launch_bounds__(256) k_head3(Head3Args a)
+{
+    int blk = blockIdx.x, l = 0;
+    if (blk >= a.blocks[0]) { blk -= a.blocks[0]; l = 1; if (blk >= a.blocks[1]) { blk -= a.blocks[1]; l = 2; } }
+    const HeadArgs &h = a.lv[l];
+    const int i = blk * 256 + threadIdx.x;
+    if (i < h.h * h.w) head_anchor(h, i, blockIdx.y);
+}
+
+__device__ __forceinline__ void head_anchor(const HeadArgs &a, int i, int b)
+{
+    const int hw = a.h * a.w;
     const size_t pix = (size_t)b * hw + i;
     const __half *bp = a.box + pix * a.ldb;
     float d[4];
@@ -1849,6 +1866,29 @@ int rva_upsample2x_nhwc_f16(rva_ctx *ctx, const void *in, int ldi, void *out, in
     if (!ctx || !in || !out || C % 8 || ldi % 8 || ldo % 8) return rva_fail(ctx, RVA_ERR_ARG, "rva_upsample2x_nhwc_f16: bad argument");
     const long n = (long)batch * H * 2 * W * 2 * (C / 8);
     k_upsample2<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream_>>>((const __half *)in, ldi, (__half *)out, ldo, batch, H, W, C);
+    RVA_HIP(ctx, hipGetLastError());
+    return RVA_OK;
+}
+
+int rva_yolo_head3_f16(rva_ctx *ctx, const void *const *box_logits, const int32_t *ldb, const void *const *cls_logits,
+                       const int32_t *ldc, void *out, int batch, const int32_t *h, const int32_t *w, int nc, int anchors_total,
+                       const float *strides, rva_stream_t stream_)
+{
+    if (!ctx || !box_logits || !cls_logits || !ldb || !ldc || !h || !w || !strides || !out || nc % 8)
+        return rva_fail(ctx, RVA_ERR_ARG, "rva_yolo_head3_f16: bad argument");
+    Head3Args a{};
+    int a0 = 0, total = 0;
+    for (int l = 0; l < 3; ++l) {
+        if (!box_logits[l] || !cls_logits[l] || ldb[l] % 8 || ldc[l] % 8 || h[l] <= 0 || w[l] <= 0)
+            return rva_fail(ctx, RVA_ERR_ARG, "rva_yolo_head3_f16: bad level %d", l);
+        a.lv[l] = HeadArgs{(const __half *)box_logits[l], ldb[l], (const __half *)cls_logits[l], ldc[l], (__half *)out, batch,
+                           h[l], w[l], nc, anchors_total, a0, strides[l]};
+        a.blocks[l] = rva_ceil_div(h[l] * w[l], 256);
+        total += a.blocks[l];
+        a0 += h[l] * w[l];
+    }
+    if (a0 != anchors_total) return rva_fail(ctx, RVA_ERR_ARG, "rva_yolo_head3_f16: anchors_total != sum of h*w");
+    k_head3<<<dim3(total, batch), 256, 0, (hipStream_t)stream_>>>(a);
     RVA_HIP(ctx, hipGetLastError());
     return RVA_OK;
 }

@@ -251,6 +251,7 @@ class FusedYoloV8:
         self.A = A
         self.out = torch.empty((B, 4 + self.nc, A), dtype=torch.float16, device=self.dev)
         a0 = 0
+        levels = []
         for lvl, (feat, hh, ww, stride) in enumerate(((n3, h3, w3, 8.0), (m4, h4, w4, 16.0), (m5, h5, w5, 32.0))):
             box, cls = net.detect.box[lvl], net.detect.cls[lvl]
             m = B * hh * ww
@@ -267,13 +268,19 @@ class FusedYoloV8:
             self._conv([box[0], cls[0]], feat, first, hh, ww)
             self._conv(box[1], b1, b2, hh, ww); self._conv(box[2], b2, bo, hh, ww)
             self._conv(cls[1], k1, k2, hh, ww); self._conv(cls[2], k2, ko, hh, ww)
-            B_, nc = B, self.nc
-
-            def head(stream, bo=bo, ko=ko, hh=hh, ww=ww, a0=a0, stride=stride):
-                ctx.check(L.rva_yolo_head_f16(ctx.handle, bo.ptr, bo.ld, ko.ptr, ko.ld, _p(self.out), B_, hh, ww, nc, A, a0,
-                                              C.c_float(stride), stream), "yolo_head")
-            self._steps.append(head)
+            levels.append((bo, ko, hh, ww, stride))
             a0 += hh * ww
+        # DFL + dist2bbox + sigmoid of the three levels in one launch
+        bp, _k1 = N.ptr_array([lv[0].ptr.value for lv in levels]); kp, _k2 = N.ptr_array([lv[1].ptr.value for lv in levels])
+        lb, _k3 = N.i32_array([lv[0].ld for lv in levels]); lc, _k4 = N.i32_array([lv[1].ld for lv in levels])
+        hs, _k5 = N.i32_array([lv[2] for lv in levels]); ws, _k6 = N.i32_array([lv[3] for lv in levels])
+        st = (C.c_float * 3)(*[lv[4] for lv in levels])
+        self._keep += [_k1, _k2, _k3, _k4, _k5, _k6, st]
+        B_, nc = B, self.nc
+
+        def head(stream):
+            ctx.check(L.rva_yolo_head3_f16(ctx.handle, bp, lb, kp, lc, _p(self.out), B_, hs, ws, nc, A, st, stream), "yolo_head3")
+        self._steps.append(head)
 
     # -- per-layer kernel selection ---------------------------------------------------------------------
     def autotune(self, reps: int = 5) -> None:
