@@ -247,9 +247,11 @@ int rva_conv_num_variants(void);
 int rva_conv2d_nhwc_f16(rva_ctx *ctx, const void *in, int ldi, const void *weights, const float *bias,
                         void *out, int ldo, const void *residual, int ldr, int batch, int H, int W, int Cin,
                         int Cout, int ksize, int stride, int act, rva_stream_t stream);
-/* Same with an explicit kernel variant (0 = heuristic; 1-4 gather, 5-8 resident-chunk, 9-12 row-reuse, 13-16 gather with 64-channel K-steps,
- * 17-20 row-reuse with two K-steps of loads in flight): lets
- * a plan time the applicable variants per layer once and keep the fastest.  RVA_ERR_ARG if not applicable. */
+/* Same with an explicit kernel variant, so that a plan can time the applicable variants per layer once and keep the
+ * fastest (0 = heuristic; 1..rva_conv_num_variants() = one kernel family and tile each, listed beside the dispatch in
+ * csrc/rva_conv.hip: register-staged gather / resident-chunk / row-reuse kernels, and the LDS-DMA large-tile kernels
+ * -- row reuse for 3x3 stride 1, gather with 64- or 32-channel K-steps for 1x1 and strided 3x3).  RVA_ERR_ARG if a
+ * variant does not apply to the shape. */
 int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *weights, const float *bias,
                           void *out, int ldo, const void *residual, int ldr, int batch, int H, int W, int Cin,
                           int Cout, int ksize, int stride, int act, int variant, rva_stream_t stream);
