@@ -1557,9 +1557,146 @@ hipError_t launch_gbig(ConvArgs &a, int ksize, hipStream_t s)
     return ksize == 1 ? launch_gbig1<BM, BN, WGM, WGN, NSLOT, 1, BK>(a, s) : launch_gbig1<BM, BN, WGM, WGN, NSLOT, 3, BK>(a, s);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The first downsampling convolution (3x3 stride 2, Cin = 32, Cout <= 64) as a patch kernel.  It is the one strided
+// layer whose weights (9 x 64 x 32 halfs = 36 KB) fit LDS for the whole launch, and at 320x320 the gather kernels
+// re-fetch every input pixel ~2.25 times through the per-CU vector-memory path (96-100 us against an HBM roofline
+// of 52 us).  Persistent blocks, two per CU: weights resident; per 4 x 32 output tile the 9 x 65 input patch is
+// brought in ONCE by LDS-DMA (one patch buffer, reused as the output stage; the two blocks of a CU overlap each other).
+// The patch is stored as two column-parity planes, LDS row = ((py*2 + (px & 1)) * 33 + (px >> 1)), so that the 16
+// lanes of a B fragment (consecutive output x, i.e. input x of stride 2) read CONSECUTIVE 64-byte rows (swz32).
+struct S2Args {
+    const __half *in; int ldi;
+    const __half *w; const float *bias;
+    __half *out; int ldo;
+    int B, H, W, Ho, Wo, Cout, CoutPad, act, tiles_x, tiles_y, total;
+};
+
+__global__ void __launch_bounds__(256) k_conv3s2_c32(S2Args a)
+{
+    constexpr int TH = 4, TW = 32, PH = 2 * TH + 1, CW = TW + 1;
+    constexpr int PROWS = PH * 2 * CW;                     // 594 patch pixels (LDS rows of 64 B)
+    constexpr int PPIECES = (PROWS + 15) / 16;             // 38
+    constexpr int WPIECES = 9 * 64 / 16;                   // 36
+    constexpr int SROW = 72;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __half *wl = (__half *)smem;                           // [9 taps][64 co][32]   (swz32 rows)
+    __half *patch = wl + WPIECES * 512;                    // [PPIECES * 16][32]   one buffer: two blocks share a CU instead
+    __half *stage = patch;                                 // [128][SROW] output staging reuses the (dead) patch
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane >> 2, lp = lane & 3;
+    const int tiles_img = a.tiles_x * a.tiles_y;
+
+    float4 bvs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bvs[i] = *reinterpret_cast<const float4 *>(a.bias + 16 * i + (lane >> 4) * 4);
+
+    // weights: once per block
+#pragma unroll
+    for (int k = 0; k < WPIECES / 4; ++k) {
+        const int idx = wv + 4 * k, row = idx * 16 + lrow;          // row = tap * 64 + co
+        const int tap = row >> 6, co = min(row & 63, a.CoutPad - 1);
+        const __half *src = a.w + (size_t)(co * 9 + tap) * 32 + ((lp - 2 * (row >> 2)) & 3) * 8;
+        __builtin_amdgcn_global_load_lds((glb_vptr)src, (lds_vptr)(wl + idx * 512), 16, 0, 0);
+    }
+    auto issue_patch = [&](int t) {
+        const int b = t / tiles_img, r2 = t - b * tiles_img, ty = r2 / a.tiles_x, tx = r2 - ty * a.tiles_x;
+        const int iy_base = 2 * ty * TH - 1, ix_base = 2 * tx * TW - 1;
+        __half *dst = patch;
+#pragma unroll
+        for (int k = 0; k < (PPIECES + 3) / 4; ++k) {
+            const int idx = wv + 4 * k;
+            if (idx < PPIECES) {
+                const int row = idx * 16 + lrow;
+                const int rc = min(row, PROWS - 1);
+                const int pr = rc / CW, c = rc - pr * CW;           // pr = py * 2 + parity
+                const int iy = iy_base + (pr >> 1), ix = ix_base + 2 * c + (pr & 1);
+                const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                const int q = ok ? (b * a.H + iy) * a.W + ix : 0;
+                const __half *src = a.in + (size_t)q * a.ldi + ((lp - 2 * (row >> 2)) & 3) * 8;
+                __builtin_amdgcn_global_load_lds((glb_vptr)src, (lds_vptr)(dst + idx * 512), 16, 0, 0);
+            }
+        }
+    };
+
+    const h8 hz = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int t = blockIdx.x; t < a.total; t += gridDim.x) {
+        issue_patch(t);
+        wait_vm<0>();
+        __builtin_amdgcn_s_barrier();        // this tile's patch (and the weights) are in LDS
+        const int b = t / tiles_img, r2 = t - b * tiles_img, ty = r2 / a.tiles_x, tx = r2 - ty * a.tiles_x;
+        const int oy = ty * TH + wv;
+        // tap validity of this lane's two pixels (bit = dy * 3 + dx)
+        int vm[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ox = tx * TW + 16 * j + (lane & 15);
+            int m = 0;
+            if (oy < a.Ho && ox < a.Wo) {
+#pragma unroll
+                for (int tp = 0; tp < 9; ++tp)
+                    if ((unsigned)(2 * oy - 1 + tp / 3) < (unsigned)a.H && (unsigned)(2 * ox - 1 + tp % 3) < (unsigned)a.W) m |= 1 << tp;
+            }
+            vm[j] = m;
+        }
+        f4 acc[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+        const __half *pp = patch;
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) {
+            const int dy = tp / 3, dx = tp % 3;
+            const int rb = ((2 * wv + dy) * 2 + (dx & 1)) * CW + (dx >> 1) + (lane & 15);
+            h8 bf[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                bf[j] = *reinterpret_cast<const h8 *>(pp + swz32(rb + 16 * j, lane >> 4));
+                if (!((vm[j] >> tp) & 1)) bf[j] = hz;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const h8 af = *reinterpret_cast<const h8 *>(wl + swz32(tp * 64 + 16 * i + (lane & 15), lane >> 4));
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        __syncthreads();                     // every wave is done reading the patch: reuse it as the output stage
+        // epilogue: bias + SiLU -> stage -> 16-byte row stores
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int co = 16 * i + (lane >> 4) * 4;
+            const float4 bv = bvs[i];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float v0 = acc[i][j][0] + bv.x, v1 = acc[i][j][1] + bv.y, v2 = acc[i][j][2] + bv.z, v3 = acc[i][j][3] + bv.w;
+                if (a.act) { v0 = silu_f(v0); v1 = silu_f(v1); v2 = silu_f(v2); v3 = silu_f(v3); }
+                const int px = wv * TW + 16 * j + (lane & 15);
+                __half2 lo = __floats2half2_rn(v0, v1), hi = __floats2half2_rn(v2, v3);
+                uint2 pk;
+                pk.x = *reinterpret_cast<uint32_t *>(&lo);
+                pk.y = *reinterpret_cast<uint32_t *>(&hi);
+                *reinterpret_cast<uint2 *>(stage + (size_t)px * SROW + co) = pk;
+            }
+        }
+        __syncthreads();
+        const int cpr = a.Cout >> 3;
+        for (int q = tid; q < TH * TW * cpr; q += 256) {
+            const int px = q / cpr, pc = q - px * cpr;
+            const int yy = ty * TH + px / TW, xx = tx * TW + px % TW;
+            if (yy < a.Ho && xx < a.Wo)
+                *reinterpret_cast<uint4 *>(a.out + ((size_t)(b * a.Ho + yy) * a.Wo + xx) * a.ldo + pc * 8) =
+                    *reinterpret_cast<const uint4 *>(stage + (size_t)px * SROW + pc * 8);
+        }
+        __syncthreads();                     // stage fully read before the next patch lands on it
+    }
+}
+
 }  // namespace
 
-#define RVA_CONV_VARIANTS 42
+#define RVA_CONV_VARIANTS 43
 
 extern "C" {
 #ifdef RVA_ROW_STAMPS
@@ -1578,6 +1715,7 @@ int rva_dbg_read_stamps(unsigned long long *host) { return (int)hipMemcpyFromSym
 //   33..38 large-tile LDS-DMA gather kernel with 64-channel K-steps (1x1; 3x3 stride 1 or 2; Cin % 64 == 0):
 //          <256,128> <128,128> <256,64> <128,64> 3-slot, <128,128> <256,64> <192,128> 2-slot
 //   40..42 the same with 32-channel K-steps (Cin % 32 == 0): <256,64> 3-slot, <128,64> 3-slot, <256,64> 2-slot
+//   43     patch kernel for 3x3 stride 2 with Cin = 32, Cout <= 64 (weights resident, input patch staged once per tile)
 int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *weights, const float *bias, void *out,
                           int ldo, const void *residual, int ldr, int batch, int H, int W, int Cin, int Cout, int ksize,
                           int stride, int act, int variant, rva_stream_t stream_);
@@ -1630,6 +1768,22 @@ int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *wei
                                                  stride, act, pick, stream_);
             if (rc == RVA_OK) return rc;
         }
+    }
+    if (variant == 43) {
+        // patch kernel of the first downsampling convolution (3x3 stride 2, Cin = 32, Cout <= 64, no residual)
+        if (!(ksize == 3 && stride == 2 && Cin == 32 && Cout <= 64 && !residual))
+            return rva_fail(ctx, RVA_ERR_ARG, "conv variant %d not applicable here", variant);
+        S2Args g{a.in, ldi, a.w, bias, a.out, ldo, batch, H, W, a.Ho, a.Wo, Cout, cpad, act, rva_ceil_div(a.Wo, 32), rva_ceil_div(a.Ho, 4), 0};
+        g.total = g.tiles_x * g.tiles_y * batch;
+        constexpr size_t smem = (size_t)36 * 1024 + 38 * 1024;      // 74 KB: two blocks per CU
+        static bool attr = false;
+        if (!attr) {
+            RVA_HIP(ctx, hipFuncSetAttribute((const void *)k_conv3s2_c32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            attr = true;
+        }
+        k_conv3s2_c32<<<g.total < 2 * num_cus ? g.total : 2 * num_cus, 256, smem, s>>>(g);
+        RVA_HIP(ctx, hipGetLastError());
+        return RVA_OK;
     }
     if (variant >= 33) {
         // large-tile LDS-DMA gather kernel, 64-channel K-steps (1x1, and 3x3 of either stride; Cin % 64 == 0)
