@@ -1569,53 +1569,63 @@ struct S2Args {
     const __half *in; int ldi;
     const __half *w; const float *bias;
     __half *out; int ldo;
+    const __half *res; int ldr;
     int B, H, W, Ho, Wo, Cout, CoutPad, act, tiles_x, tiles_y, total;
 };
 
-__global__ void __launch_bounds__(256) k_conv3s2_c32(S2Args a)
+template <int STRIDE, int CO, int NWV>
+__global__ void __launch_bounds__(NWV * 64) k_conv3_patch_c32(S2Args a)
 {
-    constexpr int TH = 4, TW = 32, PH = 2 * TH + 1, CW = TW + 1;
-    constexpr int PROWS = PH * 2 * CW;                     // 594 patch pixels (LDS rows of 64 B)
-    constexpr int PPIECES = (PROWS + 15) / 16;             // 38
-    constexpr int WPIECES = 9 * 64 / 16;                   // 36
-    constexpr int SROW = 72;
+    // output tile = NWV rows x 32 pixels (one wave per row); STRIDE 2: patch (2*NWV+1) x 65 as two column-parity planes,
+    // LDS row = (py*2 + (px & 1)) * 33 + (px >> 1);  STRIDE 1: patch (NWV+2) x 34, LDS row = py * 34 + px
+    constexpr int TH = NWV, TW = 32, NT = NWV * 64;
+    constexpr int PH = STRIDE == 2 ? 2 * TH + 1 : TH + 2;
+    constexpr int CW = STRIDE == 2 ? TW + 1 : TW + 2;                      // columns per (parity) plane
+    constexpr int PROWS = STRIDE == 2 ? PH * 2 * CW : PH * CW;
+    constexpr int PPIECES = (PROWS + 15) / 16;
+    constexpr int WPIECES = 9 * CO / 16;
+    constexpr int FN = CO / 16;
+    constexpr int SROW = CO + 8;
+    static_assert(TH * TW * SROW * 2 <= PPIECES * 1024, "the output stage reuses the patch buffer");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __half *wl = (__half *)smem;                           // [9 taps][64 co][32]   (swz32 rows)
-    __half *patch = wl + WPIECES * 512;                    // [PPIECES * 16][32]   one buffer: two blocks share a CU instead
-    __half *stage = patch;                                 // [128][SROW] output staging reuses the (dead) patch
+    __half *wl = (__half *)smem;                           // [9 taps][CO][32]   (swz32 rows)
+    __half *patch = wl + WPIECES * 512;                    // [PPIECES * 16][32]   one buffer: several blocks share a CU instead
+    __half *stage = patch;                                 // [TH*TW][SROW] output staging reuses the (dead) patch
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lrow = lane >> 2, lp = lane & 3;
     const int tiles_img = a.tiles_x * a.tiles_y;
 
-    float4 bvs[4];
+    float4 bvs[FN];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) bvs[i] = *reinterpret_cast<const float4 *>(a.bias + 16 * i + (lane >> 4) * 4);
+    for (int i = 0; i < FN; ++i) bvs[i] = *reinterpret_cast<const float4 *>(a.bias + min(16 * i + (lane >> 4) * 4, a.CoutPad - 4));
 
     // weights: once per block
 #pragma unroll
-    for (int k = 0; k < WPIECES / 4; ++k) {
-        const int idx = wv + 4 * k, row = idx * 16 + lrow;          // row = tap * 64 + co
-        const int tap = row >> 6, co = min(row & 63, a.CoutPad - 1);
-        const __half *src = a.w + (size_t)(co * 9 + tap) * 32 + ((lp - 2 * (row >> 2)) & 3) * 8;
-        __builtin_amdgcn_global_load_lds((glb_vptr)src, (lds_vptr)(wl + idx * 512), 16, 0, 0);
+    for (int k = 0; k < (WPIECES + NWV - 1) / NWV; ++k) {
+        const int idx = wv + NWV * k;
+        if (idx < WPIECES) {
+            const int row = idx * 16 + lrow;                        // row = tap * CO + co
+            const int tap = row / CO, co = min(row - tap * CO, a.CoutPad - 1);
+            const __half *src = a.w + (size_t)(co * 9 + tap) * 32 + ((lp - 2 * (row >> 2)) & 3) * 8;
+            __builtin_amdgcn_global_load_lds((glb_vptr)src, (lds_vptr)(wl + idx * 512), 16, 0, 0);
+        }
     }
     auto issue_patch = [&](int t) {
         const int b = t / tiles_img, r2 = t - b * tiles_img, ty = r2 / a.tiles_x, tx = r2 - ty * a.tiles_x;
-        const int iy_base = 2 * ty * TH - 1, ix_base = 2 * tx * TW - 1;
-        __half *dst = patch;
+        const int iy_base = STRIDE * ty * TH - 1, ix_base = STRIDE * tx * TW - 1;
 #pragma unroll
-        for (int k = 0; k < (PPIECES + 3) / 4; ++k) {
-            const int idx = wv + 4 * k;
+        for (int k = 0; k < (PPIECES + NWV - 1) / NWV; ++k) {
+            const int idx = wv + NWV * k;
             if (idx < PPIECES) {
                 const int row = idx * 16 + lrow;
                 const int rc = min(row, PROWS - 1);
-                const int pr = rc / CW, c = rc - pr * CW;           // pr = py * 2 + parity
-                const int iy = iy_base + (pr >> 1), ix = ix_base + 2 * c + (pr & 1);
+                const int pr = rc / CW, c = rc - pr * CW;           // STRIDE 2: pr = py * 2 + parity
+                const int iy = iy_base + (STRIDE == 2 ? pr >> 1 : pr), ix = ix_base + (STRIDE == 2 ? 2 * c + (pr & 1) : c);
                 const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
                 const int q = ok ? (b * a.H + iy) * a.W + ix : 0;
                 const __half *src = a.in + (size_t)q * a.ldi + ((lp - 2 * (row >> 2)) & 3) * 8;
-                __builtin_amdgcn_global_load_lds((glb_vptr)src, (lds_vptr)(dst + idx * 512), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((glb_vptr)src, (lds_vptr)(patch + idx * 512), 16, 0, 0);
             }
         }
     };
@@ -1636,29 +1646,28 @@ __global__ void __launch_bounds__(256) k_conv3s2_c32(S2Args a)
             if (oy < a.Ho && ox < a.Wo) {
 #pragma unroll
                 for (int tp = 0; tp < 9; ++tp)
-                    if ((unsigned)(2 * oy - 1 + tp / 3) < (unsigned)a.H && (unsigned)(2 * ox - 1 + tp % 3) < (unsigned)a.W) m |= 1 << tp;
+                    if ((unsigned)(STRIDE * oy - 1 + tp / 3) < (unsigned)a.H && (unsigned)(STRIDE * ox - 1 + tp % 3) < (unsigned)a.W) m |= 1 << tp;
             }
             vm[j] = m;
         }
-        f4 acc[4][2];
+        f4 acc[FN][2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < FN; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
-        const __half *pp = patch;
 #pragma unroll
         for (int tp = 0; tp < 9; ++tp) {
             const int dy = tp / 3, dx = tp % 3;
-            const int rb = ((2 * wv + dy) * 2 + (dx & 1)) * CW + (dx >> 1) + (lane & 15);
+            const int rb = (STRIDE == 2 ? ((2 * wv + dy) * 2 + (dx & 1)) * CW + (dx >> 1) : (wv + dy) * CW + dx) + (lane & 15);
             h8 bf[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                bf[j] = *reinterpret_cast<const h8 *>(pp + swz32(rb + 16 * j, lane >> 4));
+                bf[j] = *reinterpret_cast<const h8 *>(patch + swz32(rb + 16 * j, lane >> 4));
                 if (!((vm[j] >> tp) & 1)) bf[j] = hz;
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const h8 af = *reinterpret_cast<const h8 *>(wl + swz32(tp * 64 + 16 * i + (lane & 15), lane >> 4));
+            for (int i = 0; i < FN; ++i) {
+                const h8 af = *reinterpret_cast<const h8 *>(wl + swz32(tp * CO + 16 * i + (lane & 15), lane >> 4));
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[j], acc[i][j], 0, 0, 0);
             }
@@ -1666,7 +1675,7 @@ __global__ void __launch_bounds__(256) k_conv3s2_c32(S2Args a)
         __syncthreads();                     // every wave is done reading the patch: reuse it as the output stage
         // epilogue: bias + SiLU -> stage -> 16-byte row stores
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < FN; ++i) {
             const int co = 16 * i + (lane >> 4) * 4;
             const float4 bv = bvs[i];
 #pragma unroll
@@ -1683,20 +1692,51 @@ __global__ void __launch_bounds__(256) k_conv3s2_c32(S2Args a)
         }
         __syncthreads();
         const int cpr = a.Cout >> 3;
-        for (int q = tid; q < TH * TW * cpr; q += 256) {
+        for (int q = tid; q < TH * TW * cpr; q += NT) {
             const int px = q / cpr, pc = q - px * cpr;
             const int yy = ty * TH + px / TW, xx = tx * TW + px % TW;
-            if (yy < a.Ho && xx < a.Wo)
-                *reinterpret_cast<uint4 *>(a.out + ((size_t)(b * a.Ho + yy) * a.Wo + xx) * a.ldo + pc * 8) =
-                    *reinterpret_cast<const uint4 *>(stage + (size_t)px * SROW + pc * 8);
+            if (yy < a.Ho && xx < a.Wo) {
+                uint4 v = *reinterpret_cast<const uint4 *>(stage + (size_t)px * SROW + pc * 8);
+                const size_t m = (size_t)(b * a.Ho + yy) * a.Wo + xx;
+                if (a.res) {
+                    const uint4 r = *reinterpret_cast<const uint4 *>(a.res + m * a.ldr + pc * 8);
+                    __half2 *vh = reinterpret_cast<__half2 *>(&v);
+                    const __half2 *rh = reinterpret_cast<const __half2 *>(&r);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float2 x = __half22float2(vh[u]), y = __half22float2(rh[u]);
+                        vh[u] = __floats2half2_rn(x.x + y.x, x.y + y.y);
+                    }
+                }
+                *reinterpret_cast<uint4 *>(a.out + m * a.ldo + pc * 8) = v;
+            }
         }
         __syncthreads();                     // stage fully read before the next patch lands on it
     }
 }
 
+template <int STRIDE, int CO, int NWV>
+hipError_t launch_patch(S2Args &g, int num_cus, hipStream_t s)
+{
+    constexpr int PROWS = STRIDE == 2 ? (2 * NWV + 1) * 2 * 33 : (NWV + 2) * 34;
+    constexpr size_t smem = (size_t)(9 * CO / 16 + (PROWS + 15) / 16) * 1024;
+    constexpr int per_cu = smem <= 32 * 1024 ? 4 : smem <= 53 * 1024 ? 3 : smem <= 80 * 1024 ? 2 : 1;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_conv3_patch_c32<STRIDE, CO, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    g.tiles_x = rva_ceil_div(g.Wo, 32); g.tiles_y = rva_ceil_div(g.Ho, NWV);
+    g.total = g.tiles_x * g.tiles_y * g.B;
+    const int grid = g.total < per_cu * num_cus ? g.total : per_cu * num_cus;
+    k_conv3_patch_c32<STRIDE, CO, NWV><<<grid, NWV * 64, smem, s>>>(g);
+    return hipGetLastError();
+}
+
 }  // namespace
 
-#define RVA_CONV_VARIANTS 43
+#define RVA_CONV_VARIANTS 45
 
 extern "C" {
 #ifdef RVA_ROW_STAMPS
@@ -1715,7 +1755,8 @@ int rva_dbg_read_stamps(unsigned long long *host) { return (int)hipMemcpyFromSym
 //   33..38 large-tile LDS-DMA gather kernel with 64-channel K-steps (1x1; 3x3 stride 1 or 2; Cin % 64 == 0):
 //          <256,128> <128,128> <256,64> <128,64> 3-slot, <128,128> <256,64> <192,128> 2-slot
 //   40..42 the same with 32-channel K-steps (Cin % 32 == 0): <256,64> 3-slot, <128,64> 3-slot, <256,64> 2-slot
-//   43     patch kernel for 3x3 stride 2 with Cin = 32, Cout <= 64 (weights resident, input patch staged once per tile)
+//   43..45 patch kernels for Cin = 32 (weights resident, input patch staged once per tile): 3x3 stride 2 with Cout <= 64;
+//          3x3 stride 1 with Cout <= 32, 4- and 8-row tiles
 int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *weights, const float *bias, void *out,
                           int ldo, const void *residual, int ldr, int batch, int H, int W, int Cin, int Cout, int ksize,
                           int stride, int act, int variant, rva_stream_t stream_);
@@ -1769,21 +1810,19 @@ int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *wei
             if (rc == RVA_OK) return rc;
         }
     }
-    if (variant == 43) {
-        // patch kernel of the first downsampling convolution (3x3 stride 2, Cin = 32, Cout <= 64, no residual)
-        if (!(ksize == 3 && stride == 2 && Cin == 32 && Cout <= 64 && !residual))
-            return rva_fail(ctx, RVA_ERR_ARG, "conv variant %d not applicable here", variant);
-        S2Args g{a.in, ldi, a.w, bias, a.out, ldo, batch, H, W, a.Ho, a.Wo, Cout, cpad, act, rva_ceil_div(a.Wo, 32), rva_ceil_div(a.Ho, 4), 0};
-        g.total = g.tiles_x * g.tiles_y * batch;
-        constexpr size_t smem = (size_t)36 * 1024 + 38 * 1024;      // 74 KB: two blocks per CU
-        static bool attr = false;
-        if (!attr) {
-            RVA_HIP(ctx, hipFuncSetAttribute((const void *)k_conv3s2_c32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            attr = true;
+    if (variant >= 43) {
+        // patch kernels for Cin = 32 (weights resident in LDS): 43 = 3x3 stride 2, Cout <= 64 (the first downsampling
+        // convolution); 44 / 45 = 3x3 stride 1, Cout <= 32, tiles of 4 / 8 rows (the 32 -> 32 bottleneck convolutions)
+        hipError_t ev = hipErrorInvalidValue;
+        S2Args g{a.in, ldi, a.w, bias, a.out, ldo, a.res, ldr, batch, H, W, a.Ho, a.Wo, Cout, cpad, act, 0, 0, 0};
+        if (ksize == 3 && Cin == 32) {
+            if (variant == 43 && stride == 2 && Cout <= 64) ev = launch_patch<2, 64, 4>(g, num_cus, s);
+            else if (variant == 44 && stride == 1 && Cout <= 32) ev = launch_patch<1, 32, 4>(g, num_cus, s);
+            else if (variant == 45 && stride == 1 && Cout <= 32) ev = launch_patch<1, 32, 8>(g, num_cus, s);
         }
-        k_conv3s2_c32<<<g.total < 2 * num_cus ? g.total : 2 * num_cus, 256, smem, s>>>(g);
-        RVA_HIP(ctx, hipGetLastError());
-        return RVA_OK;
+        if (ev == hipSuccess) return RVA_OK;
+        (void)hipGetLastError();
+        return rva_fail(ctx, ev == hipErrorInvalidValue ? RVA_ERR_ARG : RVA_ERR_HIP, "conv variant %d not applicable here", variant);
     }
     if (variant >= 33) {
         // large-tile LDS-DMA gather kernel, 64-channel K-steps (1x1, and 3x3 of either stride; Cin % 64 == 0)

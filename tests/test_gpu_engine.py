@@ -185,11 +185,13 @@ def test_upcat_conv_matches_torch(shape):
     assert ran == 8
 
 
-@pytest.mark.parametrize("shape", [(2, 21, 18, 64), (1, 160, 160, 64), (3, 33, 71, 32), (2, 8, 64, 64)])
-def test_stride2_patch_kernel_matches_torch(shape):
-    """Variant 43: the patch kernel of the first downsampling convolution (3x3 stride 2, Cin = 32, no residual), odd sizes,
-    partial tiles, an output slice with a row stride."""
-    B, H, W, Cout = shape
+@pytest.mark.parametrize("shape", [(2, 21, 18, 64, 43), (1, 160, 160, 64, 43), (3, 33, 71, 32, 43), (2, 8, 64, 64, 43),
+                                   (2, 21, 18, 32, 44), (1, 160, 160, 32, 45), (3, 33, 71, 32, 45), (2, 7, 64, 16, 44)])
+def test_patch_kernels_match_torch(shape):
+    """Variants 43-45: the resident-weight patch kernels for Cin = 32 (3x3 stride 2 -> Cout <= 64; stride 1 -> Cout <= 32),
+    odd sizes, partial tiles, residual on the stride-1 form, an output slice with a row stride."""
+    B, H, W, Cout, variant = shape
+    stride = 2 if variant == 43 else 1
     Cin = 32
     g = torch.Generator().manual_seed(9)
     x = (torch.randn((B, H, W, Cin), generator=g) * 0.5).half().cuda()
@@ -200,14 +202,16 @@ def test_stride2_patch_kernel_matches_torch(shape):
     wp = torch.zeros((cpad, 9, 32), dtype=torch.float16); wp[:Cout] = w.permute(0, 2, 3, 1).reshape(Cout, 9, Cin)
     bp = torch.zeros(cpad); bp[:Cout] = b
     wp, bp = wp.cuda(), bp.cuda()
-    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
     out = torch.full((B, Ho, Wo, Cout + 8), 7.0, dtype=torch.float16, device="cuda")
+    res = (torch.randn((B, Ho, Wo, Cout), generator=g) * 0.5).half().cuda() if stride == 1 else None
     rc = L.rva_conv2d_nhwc_f16_v(ctx.handle, C.c_void_p(x.data_ptr()), Cin, C.c_void_p(wp.data_ptr()), C.c_void_p(bp.data_ptr()),
-                                 C.c_void_p(out.data_ptr() + 16), Cout + 8, None, 0, B, H, W, Cin, Cout, 3, 2, 1, 43,
+                                 C.c_void_p(out.data_ptr() + 16), Cout + 8, C.c_void_p(res.data_ptr()) if res is not None else None,
+                                 Cout if res is not None else 0, B, H, W, Cin, Cout, 3, stride, 1, variant,
                                  C.c_void_p(torch.cuda.current_stream().cuda_stream))
     ctx.check(rc)
     torch.cuda.synchronize()
-    want = _conv_ref(x, w.cuda(), b.cuda(), 3, 2, 1, None)
+    want = _conv_ref(x, w.cuda(), b.cuda(), 3, stride, 1, res)
     err = (out[..., 8:].float() - want).abs().max().item()
     assert err < 2e-2 + 2e-3 * want.abs().max().item(), err
     assert torch.all(out[..., :8] == 7.0)
