@@ -1573,28 +1573,36 @@ struct S2Args {
     int B, H, W, Ho, Wo, Cout, CoutPad, act, tiles_x, tiles_y, total;
 };
 
-template <int STRIDE, int CO, int NWV>
-__global__ void __launch_bounds__(NWV * 64) k_conv3_patch_c32(S2Args a)
+template <int STRIDE, int CIN, int CO, int NWV, int NBUF>
+__global__ void __launch_bounds__(NWV * 64) k_conv3_patch(S2Args a)
 {
     // output tile = NWV rows x 32 pixels (one wave per row); STRIDE 2: patch (2*NWV+1) x 65 as two column-parity planes,
-    // LDS row = (py*2 + (px & 1)) * 33 + (px >> 1);  STRIDE 1: patch (NWV+2) x 34, LDS row = py * 34 + px
+    // LDS row = (py*2 + (px & 1)) * 33 + (px >> 1);  STRIDE 1: patch (NWV+2) x 34, LDS row = py * 34 + px.
+    // CIN 32: 64-byte rows (swz32), 16 rows per 1 KiB piece;  CIN 64: 128-byte rows (chunk ^ (row & 7)), 8 rows per piece.
+    // NBUF 2: the next tile's patch is fetched under this tile's MFMAs and epilogue (one block per CU);  NBUF 1: one
+    // patch buffer, several blocks per CU overlap each other instead.
+    static_assert(CIN == 32 || CIN == 64, "input channels");
     constexpr int TH = NWV, TW = 32, NT = NWV * 64;
     constexpr int PH = STRIDE == 2 ? 2 * TH + 1 : TH + 2;
     constexpr int CW = STRIDE == 2 ? TW + 1 : TW + 2;                      // columns per (parity) plane
     constexpr int PROWS = STRIDE == 2 ? PH * 2 * CW : PH * CW;
-    constexpr int PPIECES = (PROWS + 15) / 16;
-    constexpr int WPIECES = 9 * CO / 16;
-    constexpr int FN = CO / 16;
+    constexpr int RPP = 512 / CIN, LPR = CIN / 8;                          // rows per piece, lanes per row
+    constexpr int PPIECES = (PROWS + RPP - 1) / RPP;
+    constexpr int WPIECES = 9 * CO / RPP;
+    constexpr int FN = CO / 16, KCH = CIN / 32;
     constexpr int SROW = CO + 8;
-    static_assert(TH * TW * SROW * 2 <= PPIECES * 1024, "the output stage reuses the patch buffer");
+    static_assert(TH * TW * SROW * 2 <= PPIECES * 1024, "the output stage reuses a patch buffer");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __half *wl = (__half *)smem;                           // [9 taps][CO][32]   (swz32 rows)
-    __half *patch = wl + WPIECES * 512;                    // [PPIECES * 16][32]   one buffer: several blocks share a CU instead
-    __half *stage = patch;                                 // [TH*TW][SROW] output staging reuses the (dead) patch
+    __half *wl = (__half *)smem;                           // [9 taps][CO][CIN]   (swizzled rows)
+    __half *patch0 = wl + WPIECES * 512;                   // [NBUF][PPIECES * RPP][CIN]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lrow = lane >> 2, lp = lane & 3;
+    const int lrow = lane / LPR, lp = lane % LPR;
     const int tiles_img = a.tiles_x * a.tiles_y;
+    // source chunk (x8 halfs) of LDS row `row`, physical chunk lp: inverse of the swizzle the fragment reads apply
+    auto src_c8 = [&](int row) { return (CIN == 64 ? (lp ^ (row & 7)) : ((lp - 2 * (row >> 2)) & 3)) * 8; };
+    // half offset of (row, 16-byte chunk c) inside a swizzled buffer
+    auto lds_off = [&](int row, int c) { return CIN == 64 ? row * 64 + ((c ^ (row & 7)) << 3) : swz32(row, c); };
 
     float4 bvs[FN];
 #pragma unroll
@@ -1605,36 +1613,42 @@ __global__ void __launch_bounds__(NWV * 64) k_conv3_patch_c32(S2Args a)
     for (int k = 0; k < (WPIECES + NWV - 1) / NWV; ++k) {
         const int idx = wv + NWV * k;
         if (idx < WPIECES) {
-            const int row = idx * 16 + lrow;                        // row = tap * CO + co
+            const int row = idx * RPP + lrow;                       // row = tap * CO + co
             const int tap = row / CO, co = min(row - tap * CO, a.CoutPad - 1);
-            const __half *src = a.w + (size_t)(co * 9 + tap) * 32 + ((lp - 2 * (row >> 2)) & 3) * 8;
+            const __half *src = a.w + (size_t)(co * 9 + tap) * CIN + src_c8(row);
             __builtin_amdgcn_global_load_lds((glb_vptr)src, (lds_vptr)(wl + idx * 512), 16, 0, 0);
         }
     }
-    auto issue_patch = [&](int t) {
+    auto issue_patch = [&](int t, int pb) {
         const int b = t / tiles_img, r2 = t - b * tiles_img, ty = r2 / a.tiles_x, tx = r2 - ty * a.tiles_x;
         const int iy_base = STRIDE * ty * TH - 1, ix_base = STRIDE * tx * TW - 1;
+        __half *dst = patch0 + (size_t)pb * PPIECES * 512;
 #pragma unroll
         for (int k = 0; k < (PPIECES + NWV - 1) / NWV; ++k) {
             const int idx = wv + NWV * k;
             if (idx < PPIECES) {
-                const int row = idx * 16 + lrow;
+                const int row = idx * RPP + lrow;
                 const int rc = min(row, PROWS - 1);
                 const int pr = rc / CW, c = rc - pr * CW;           // STRIDE 2: pr = py * 2 + parity
                 const int iy = iy_base + (STRIDE == 2 ? pr >> 1 : pr), ix = ix_base + (STRIDE == 2 ? 2 * c + (pr & 1) : c);
                 const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
                 const int q = ok ? (b * a.H + iy) * a.W + ix : 0;
-                const __half *src = a.in + (size_t)q * a.ldi + ((lp - 2 * (row >> 2)) & 3) * 8;
-                __builtin_amdgcn_global_load_lds((glb_vptr)src, (lds_vptr)(patch + idx * 512), 16, 0, 0);
+                const __half *src = a.in + (size_t)q * a.ldi + src_c8(row);
+                __builtin_amdgcn_global_load_lds((glb_vptr)src, (lds_vptr)(dst + idx * 512), 16, 0, 0);
             }
         }
     };
 
     const h8 hz = {0, 0, 0, 0, 0, 0, 0, 0};
+    int pb = 0;
+    if (NBUF == 2 && (int)blockIdx.x < a.total) issue_patch(blockIdx.x, 0);
     for (int t = blockIdx.x; t < a.total; t += gridDim.x) {
-        issue_patch(t);
+        if (NBUF == 1) issue_patch(t, 0);
         wait_vm<0>();
-        __builtin_amdgcn_s_barrier();        // this tile's patch (and the weights) are in LDS
+        __builtin_amdgcn_s_barrier();        // this tile's patch (and the weights) are in LDS; the previous tile is done
+        if (NBUF == 2 && t + (int)gridDim.x < a.total) issue_patch(t + gridDim.x, pb ^ 1);
+        const __half *patch = patch0 + (size_t)pb * PPIECES * 512;
+        __half *stage = patch0 + (size_t)pb * PPIECES * 512;       // [TH*TW][SROW], once the patch is dead
         const int b = t / tiles_img, r2 = t - b * tiles_img, ty = r2 / a.tiles_x, tx = r2 - ty * a.tiles_x;
         const int oy = ty * TH + wv;
         // tap validity of this lane's two pixels (bit = dy * 3 + dx)
@@ -1659,17 +1673,20 @@ __global__ void __launch_bounds__(NWV * 64) k_conv3_patch_c32(S2Args a)
         for (int tp = 0; tp < 9; ++tp) {
             const int dy = tp / 3, dx = tp % 3;
             const int rb = (STRIDE == 2 ? ((2 * wv + dy) * 2 + (dx & 1)) * CW + (dx >> 1) : (wv + dy) * CW + dx) + (lane & 15);
-            h8 bf[2];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                bf[j] = *reinterpret_cast<const h8 *>(patch + swz32(rb + 16 * j, lane >> 4));
-                if (!((vm[j] >> tp) & 1)) bf[j] = hz;
-            }
+            for (int ks = 0; ks < KCH; ++ks) {
+                h8 bf[2];
 #pragma unroll
-            for (int i = 0; i < FN; ++i) {
-                const h8 af = *reinterpret_cast<const h8 *>(wl + swz32(tp * CO + 16 * i + (lane & 15), lane >> 4));
+                for (int j = 0; j < 2; ++j) {
+                    bf[j] = *reinterpret_cast<const h8 *>(patch + lds_off(rb + 16 * j, ks * 4 + (lane >> 4)));
+                    if (!((vm[j] >> tp) & 1)) bf[j] = hz;
+                }
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[j], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < FN; ++i) {
+                    const h8 af = *reinterpret_cast<const h8 *>(wl + lds_off(tp * CO + 16 * i + (lane & 15), ks * 4 + (lane >> 4)));
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[j], acc[i][j], 0, 0, 0);
+                }
             }
         }
         __syncthreads();                     // every wave is done reading the patch: reuse it as the output stage
@@ -1711,32 +1728,35 @@ __global__ void __launch_bounds__(NWV * 64) k_conv3_patch_c32(S2Args a)
                 *reinterpret_cast<uint4 *>(a.out + m * a.ldo + pc * 8) = v;
             }
         }
-        __syncthreads();                     // stage fully read before the next patch lands on it
+        if (NBUF == 1) __syncthreads();      // stage fully read before the next patch lands on it
+        else pb ^= 1;                        // two buffers: the next top-of-loop barrier orders the stage reads
     }
 }
 
-template <int STRIDE, int CO, int NWV>
+template <int STRIDE, int CIN, int CO, int NWV, int NBUF>
 hipError_t launch_patch(S2Args &g, int num_cus, hipStream_t s)
 {
+    constexpr int RPP = 512 / CIN;
     constexpr int PROWS = STRIDE == 2 ? (2 * NWV + 1) * 2 * 33 : (NWV + 2) * 34;
-    constexpr size_t smem = (size_t)(9 * CO / 16 + (PROWS + 15) / 16) * 1024;
+    constexpr size_t smem = (size_t)(9 * CO / RPP + NBUF * ((PROWS + RPP - 1) / RPP)) * 1024;
+    static_assert(smem <= 160 * 1024, "LDS budget");
     constexpr int per_cu = smem <= 32 * 1024 ? 4 : smem <= 53 * 1024 ? 3 : smem <= 80 * 1024 ? 2 : 1;
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_conv3_patch_c32<STRIDE, CO, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipError_t e = hipFuncSetAttribute((const void *)k_conv3_patch<STRIDE, CIN, CO, NWV, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
         attr = true;
     }
     g.tiles_x = rva_ceil_div(g.Wo, 32); g.tiles_y = rva_ceil_div(g.Ho, NWV);
     g.total = g.tiles_x * g.tiles_y * g.B;
     const int grid = g.total < per_cu * num_cus ? g.total : per_cu * num_cus;
-    k_conv3_patch_c32<STRIDE, CO, NWV><<<grid, NWV * 64, smem, s>>>(g);
+    k_conv3_patch<STRIDE, CIN, CO, NWV, NBUF><<<grid, NWV * 64, smem, s>>>(g);
     return hipGetLastError();
 }
 
 }  // namespace
 
-#define RVA_CONV_VARIANTS 45
+#define RVA_CONV_VARIANTS 48
 
 extern "C" {
 #ifdef RVA_ROW_STAMPS
@@ -1757,6 +1777,7 @@ int rva_dbg_read_stamps(unsigned long long *host) { return (int)hipMemcpyFromSym
 //   40..42 the same with 32-channel K-steps (Cin % 32 == 0): <256,64> 3-slot, <128,64> 3-slot, <256,64> 2-slot
 //   43..45 patch kernels for Cin = 32 (weights resident, input patch staged once per tile): 3x3 stride 2 with Cout <= 64;
 //          3x3 stride 1 with Cout <= 32, 4- and 8-row tiles
+//   46..48 patch kernels for 3x3 stride 1, Cin = 64, Cout <= 64 (double-buffered 4-row tile, 8-row tile, 4-row tile)
 int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *weights, const float *bias, void *out,
                           int ldo, const void *residual, int ldr, int batch, int H, int W, int Cin, int Cout, int ksize,
                           int stride, int act, int variant, rva_stream_t stream_);
@@ -1811,14 +1832,19 @@ int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *wei
         }
     }
     if (variant >= 43) {
-        // patch kernels for Cin = 32 (weights resident in LDS): 43 = 3x3 stride 2, Cout <= 64 (the first downsampling
+        // patch kernels (weights resident in LDS): Cin = 32: 43 = 3x3 stride 2, Cout <= 64 (the first downsampling
         // convolution); 44 / 45 = 3x3 stride 1, Cout <= 32, tiles of 4 / 8 rows (the 32 -> 32 bottleneck convolutions)
         hipError_t ev = hipErrorInvalidValue;
         S2Args g{a.in, ldi, a.w, bias, a.out, ldo, a.res, ldr, batch, H, W, a.Ho, a.Wo, Cout, cpad, act, 0, 0, 0};
         if (ksize == 3 && Cin == 32) {
-            if (variant == 43 && stride == 2 && Cout <= 64) ev = launch_patch<2, 64, 4>(g, num_cus, s);
-            else if (variant == 44 && stride == 1 && Cout <= 32) ev = launch_patch<1, 32, 4>(g, num_cus, s);
-            else if (variant == 45 && stride == 1 && Cout <= 32) ev = launch_patch<1, 32, 8>(g, num_cus, s);
+            if (variant == 43 && stride == 2 && Cout <= 64) ev = launch_patch<2, 32, 64, 4, 1>(g, num_cus, s);
+            else if (variant == 44 && stride == 1 && Cout <= 32) ev = launch_patch<1, 32, 32, 4, 1>(g, num_cus, s);
+            else if (variant == 45 && stride == 1 && Cout <= 32) ev = launch_patch<1, 32, 32, 8, 1>(g, num_cus, s);
+        } else if (ksize == 3 && Cin == 64 && stride == 1 && Cout <= 64) {
+            // 64 -> 64: 72 KB of weights resident, one block per CU
+            if (variant == 46) ev = launch_patch<1, 64, 64, 4, 2>(g, num_cus, s);         // 124 KB, two patch buffers
+            else if (variant == 47) ev = launch_patch<1, 64, 64, 8, 1>(g, num_cus, s);    // 116 KB, eight waves, one buffer
+            else if (variant == 48) ev = launch_patch<1, 64, 64, 4, 1>(g, num_cus, s);    // 98 KB
         }
         if (ev == hipSuccess) return RVA_OK;
         (void)hipGetLastError();

@@ -186,20 +186,21 @@ def test_upcat_conv_matches_torch(shape):
 
 
 @pytest.mark.parametrize("shape", [(2, 21, 18, 64, 43), (1, 160, 160, 64, 43), (3, 33, 71, 32, 43), (2, 8, 64, 64, 43),
-                                   (2, 21, 18, 32, 44), (1, 160, 160, 32, 45), (3, 33, 71, 32, 45), (2, 7, 64, 16, 44)])
+                                   (2, 21, 18, 32, 44), (1, 160, 160, 32, 45), (3, 33, 71, 32, 45), (2, 7, 64, 16, 44),
+                                   (2, 21, 18, 64, 46), (1, 80, 80, 64, 46), (3, 33, 71, 64, 47), (2, 7, 64, 32, 48), (4, 40, 40, 64, 48)])
 def test_patch_kernels_match_torch(shape):
-    """Variants 43-45: the resident-weight patch kernels for Cin = 32 (3x3 stride 2 -> Cout <= 64; stride 1 -> Cout <= 32),
+    """Variants 43-48: the resident-weight patch kernels (Cin = 32: 3x3 stride 2 -> Cout <= 64, stride 1 -> Cout <= 32; Cin = 64: stride 1 -> Cout <= 64),
     odd sizes, partial tiles, residual on the stride-1 form, an output slice with a row stride."""
     B, H, W, Cout, variant = shape
     stride = 2 if variant == 43 else 1
-    Cin = 32
+    Cin = 64 if variant >= 46 else 32
     g = torch.Generator().manual_seed(9)
     x = (torch.randn((B, H, W, Cin), generator=g) * 0.5).half().cuda()
     w = (torch.randn((Cout, Cin, 3, 3), generator=g) / (Cin * 9) ** 0.5).half()
     b = torch.randn((Cout,), generator=g) * 0.1
     L, ctx = N.lib(), ops.context()
     cpad = L.rva_conv_cout_pad(Cout)
-    wp = torch.zeros((cpad, 9, 32), dtype=torch.float16); wp[:Cout] = w.permute(0, 2, 3, 1).reshape(Cout, 9, Cin)
+    wp = torch.zeros((cpad, 9, Cin), dtype=torch.float16); wp[:Cout] = w.permute(0, 2, 3, 1).reshape(Cout, 9, Cin)
     bp = torch.zeros(cpad); bp[:Cout] = b
     wp, bp = wp.cuda(), bp.cuda()
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
