@@ -1619,21 +1619,31 @@ __global__ void __launch_bounds__(NWV * 64) k_conv3_patch(S2Args a)
             __builtin_amdgcn_global_load_lds((glb_vptr)src, (lds_vptr)(wl + idx * 512), 16, 0, 0);
         }
     }
+    // the patch position of every LDS row this lane fills is the same for all tiles: decode it once
+    constexpr int NPP = (PPIECES + NWV - 1) / NWV;
+    int pdy[NPP], pdx[NPP], pc8[NPP];
+#pragma unroll
+    for (int k = 0; k < NPP; ++k) {
+        const int row = (wv + NWV * k) * RPP + lrow;
+        const int rc = min(row, PROWS - 1);
+        const int pr = rc / CW, c = rc - pr * CW;                   // STRIDE 2: pr = py * 2 + parity
+        pdy[k] = STRIDE == 2 ? pr >> 1 : pr;
+        pdx[k] = STRIDE == 2 ? 2 * c + (pr & 1) : c;
+        pc8[k] = src_c8(row);
+    }
     auto issue_patch = [&](int t, int pb) {
         const int b = t / tiles_img, r2 = t - b * tiles_img, ty = r2 / a.tiles_x, tx = r2 - ty * a.tiles_x;
         const int iy_base = STRIDE * ty * TH - 1, ix_base = STRIDE * tx * TW - 1;
         __half *dst = patch0 + (size_t)pb * PPIECES * 512;
+        const int img = b * a.H;
 #pragma unroll
-        for (int k = 0; k < (PPIECES + NWV - 1) / NWV; ++k) {
+        for (int k = 0; k < NPP; ++k) {
             const int idx = wv + NWV * k;
             if (idx < PPIECES) {
-                const int row = idx * RPP + lrow;
-                const int rc = min(row, PROWS - 1);
-                const int pr = rc / CW, c = rc - pr * CW;           // STRIDE 2: pr = py * 2 + parity
-                const int iy = iy_base + (STRIDE == 2 ? pr >> 1 : pr), ix = ix_base + (STRIDE == 2 ? 2 * c + (pr & 1) : c);
+                const int iy = iy_base + pdy[k], ix = ix_base + pdx[k];
                 const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-                const int q = ok ? (b * a.H + iy) * a.W + ix : 0;
-                const __half *src = a.in + (size_t)q * a.ldi + src_c8(row);
+                const int q = ok ? (img + iy) * a.W + ix : 0;
+                const __half *src = a.in + (size_t)q * a.ldi + pc8[k];
                 __builtin_amdgcn_global_load_lds((glb_vptr)src, (lds_vptr)(dst + idx * 512), 16, 0, 0);
             }
         }
@@ -1739,7 +1749,7 @@ hipError_t launch_patch(S2Args &g, int num_cus, hipStream_t s)
     constexpr int RPP = 512 / CIN;
     constexpr int PROWS = STRIDE == 2 ? (2 * NWV + 1) * 2 * 33 : (NWV + 2) * 34;
     constexpr size_t smem = (size_t)(9 * CO / RPP + NBUF * ((PROWS + RPP - 1) / RPP)) * 1024;
-    static_assert(smem <= 160 * 1024, "LDS budget");
+    static_assert(smem <= 160 * 1024, "LDS budget");   // 163,840 B per CU
     constexpr int per_cu = smem <= 32 * 1024 ? 4 : smem <= 53 * 1024 ? 3 : smem <= 80 * 1024 ? 2 : 1;
     static bool attr = false;
     if (!attr) {
@@ -1756,7 +1766,7 @@ hipError_t launch_patch(S2Args &g, int num_cus, hipStream_t s)
 
 }  // namespace
 
-#define RVA_CONV_VARIANTS 48
+#define RVA_CONV_VARIANTS 49
 
 extern "C" {
 #ifdef RVA_ROW_STAMPS
@@ -1777,7 +1787,8 @@ int rva_dbg_read_stamps(unsigned long long *host) { return (int)hipMemcpyFromSym
 //   40..42 the same with 32-channel K-steps (Cin % 32 == 0): <256,64> 3-slot, <128,64> 3-slot, <256,64> 2-slot
 //   43..45 patch kernels for Cin = 32 (weights resident, input patch staged once per tile): 3x3 stride 2 with Cout <= 64;
 //          3x3 stride 1 with Cout <= 32, 4- and 8-row tiles
-//   46..48 patch kernels for 3x3 stride 1, Cin = 64, Cout <= 64 (double-buffered 4-row tile, 8-row tile, 4-row tile)
+//   46..49 patch kernels for 3x3 stride 1, Cin = 64, Cout <= 64 (double-buffered 4-row tile, 8-row tile, 4-row tile,
+//          double-buffered 8-row tile)
 int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *weights, const float *bias, void *out,
                           int ldo, const void *residual, int ldr, int batch, int H, int W, int Cin, int Cout, int ksize,
                           int stride, int act, int variant, rva_stream_t stream_);
@@ -1845,6 +1856,7 @@ int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *wei
             if (variant == 46) ev = launch_patch<1, 64, 64, 4, 2>(g, num_cus, s);         // 124 KB, two patch buffers
             else if (variant == 47) ev = launch_patch<1, 64, 64, 8, 1>(g, num_cus, s);    // 116 KB, eight waves, one buffer
             else if (variant == 48) ev = launch_patch<1, 64, 64, 4, 1>(g, num_cus, s);    // 98 KB
+            else if (variant == 49) ev = launch_patch<1, 64, 64, 8, 2>(g, num_cus, s);    // 158 KB: eight waves, two patch buffers
         }
         if (ev == hipSuccess) return RVA_OK;
         (void)hipGetLastError();
