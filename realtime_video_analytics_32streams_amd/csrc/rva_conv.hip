@@ -1650,13 +1650,23 @@ __global__ void __launch_bounds__(NWV * 64) k_conv3_patch(S2Args a)
     };
 
     const h8 hz = {0, 0, 0, 0, 0, 0, 0, 0};
+#ifdef RVA_ROW_STAMPS
+    const int st_stride = gridDim.x / 8;
+    const bool st_on = tid == 0 && st_stride > 0 && blockIdx.x % st_stride == 0 && blockIdx.x / st_stride < 8;
+    const int st_slot = st_on ? blockIdx.x / st_stride : 0;
+    int st_n = 0;
+#endif
     int pb = 0;
     if (NBUF == 2 && (int)blockIdx.x < a.total) issue_patch(blockIdx.x, 0);
     for (int t = blockIdx.x; t < a.total; t += gridDim.x) {
+        STAMP(0);
         if (NBUF == 1) issue_patch(t, 0);
         wait_vm<0>();
+        STAMP(1);
         __builtin_amdgcn_s_barrier();        // this tile's patch (and the weights) are in LDS; the previous tile is done
+        STAMP(2);
         if (NBUF == 2 && t + (int)gridDim.x < a.total) issue_patch(t + gridDim.x, pb ^ 1);
+        STAMP(3);
         const __half *patch = patch0 + (size_t)pb * PPIECES * 512;
         __half *stage = patch0 + (size_t)pb * PPIECES * 512;       // [TH*TW][SROW], once the patch is dead
         const int b = t / tiles_img, r2 = t - b * tiles_img, ty = r2 / a.tiles_x, tx = r2 - ty * a.tiles_x;
@@ -1699,7 +1709,9 @@ __global__ void __launch_bounds__(NWV * 64) k_conv3_patch(S2Args a)
                 }
             }
         }
+        STAMP(4);
         __syncthreads();                     // every wave is done reading the patch: reuse it as the output stage
+        STAMP(5);
         // epilogue: bias + SiLU -> stage -> 16-byte row stores
 #pragma unroll
         for (int i = 0; i < FN; ++i) {
@@ -1717,7 +1729,9 @@ __global__ void __launch_bounds__(NWV * 64) k_conv3_patch(S2Args a)
                 *reinterpret_cast<uint2 *>(stage + (size_t)px * SROW + co) = pk;
             }
         }
+        STAMP(6);
         __syncthreads();
+        STAMP(7);
         const int cpr = a.Cout >> 3;
         for (int q = tid; q < TH * TW * cpr; q += NT) {
             const int px = q / cpr, pc = q - px * cpr;
@@ -1738,6 +1752,7 @@ __global__ void __launch_bounds__(NWV * 64) k_conv3_patch(S2Args a)
                 *reinterpret_cast<uint4 *>(a.out + m * a.ldo + pc * 8) = v;
             }
         }
+        STAMP(8);
         if (NBUF == 1) __syncthreads();      // stage fully read before the next patch lands on it
         else pb ^= 1;                        // two buffers: the next top-of-loop barrier orders the stage reads
     }
