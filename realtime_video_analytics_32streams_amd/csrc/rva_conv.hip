@@ -3,24 +3,26 @@
 // Why these exist: profiling the PyTorch/MIOpen network (profiles/r01_a_*) shows four kernels per
 // convolution (zero-fill for split-K atomics, implicit GEMM, broadcast bias add, SiLU) plus chunk /
 // concat copies; only ~40 % of the detector time is MFMA work and most layers are HBM-bound at
-// YOLOv8 channel widths.  The kernels here do one pass per layer:
+// YOLOv8 channel widths.  The kernels here do one pass per layer.
 //
-//   k_conv_mfma<BN,WPX,KS>  implicit-GEMM convolution, 1x1 or 3x3 (stride 1/2, pad KS/2) on
-//       v_mfma_f32_16x16x32_f16.  GEMM view: D[co][px] = sum_k W[co][k] * X[px][k], k = tap*Cin + c.
-//       A operand = weights (rows = output channels), B operand = activations (columns = pixels),
-//       so a lane's 4 accumulator registers are 4 consecutive output channels of one pixel.
-//       256 threads = 4 waves, each wave owns WPX pixels x BN channels; per K-step (32 channels of
-//       one tap) the block stages [4*WPX][32] activations + [BN][32] weights through registers into
-//       padded LDS rows (80 B: conflict-free ds_read_b128), double-buffered, one barrier per step;
-//       the next step's global loads are issued before the MFMAs of the current one.
-//       Epilogue: + bias (fp32) -> SiLU -> (+ residual) -> fp16, transposed through LDS so that every
-//       pixel row leaves as full 16-byte vectors.  Input, output and residual take a row stride
-//       (ld*) and start at a channel offset, so producers write straight into concat buffers and
-//       consumers read channel slices: no cat / chunk / contiguous copies exist.
-//   k_stem      3x3 stride-2 conv on the planar fp16 tensor K1 writes (Cin = 3), bias + SiLU, NHWC out.
-//   k_maxpool5  5x5 stride-1 max pool on a channel slice (SPPF), NHWC.
-//   k_upsample2 nearest 2x upsample into a channel slice, NHWC.
-//   k_head      DFL expectation + dist2bbox + sigmoid -> [B, 4+nc, A] (anchor axis contiguous).
+// GEMM view shared by every convolution kernel: D[co][px] = sum_k W[co][k] * X[px][k], k = tap*Cin + c, on
+// v_mfma_f32_16x16x32_f16 with A = weights (rows = output channels) and B = activations (columns = pixels), so a
+// lane's 4 accumulator registers are 4 consecutive output channels of one pixel.  Epilogue: + bias (fp32) -> SiLU
+// -> (+ residual) -> fp16, transposed through LDS so that every pixel row leaves as full 16-byte vectors.  Input,
+// output and residual take a row stride (ld*) and start at a channel offset, so producers write straight into
+// concat buffers and consumers read channel slices: no cat / chunk / contiguous copies exist.
+//
+// Kernel families (rva_conv2d_nhwc_f16_v picks one by variant; the plan autotunes per layer):
+//   k_conv_mfma    gather implicit GEMM, 4 waves, operands staged through registers into swizzled LDS rows
+//   k_conv_res     persistent resident-chunk variant of the same
+//   k_conv3_row    3x3 stride 1: one staged run of raster pixels serves the three horizontal taps
+//   k_conv3_big    the same idea at 128-384 px x 64-128 ch per block, 8 waves, operands by LDS-DMA into a 2- or 3-slot
+//                  ring (counted vmcnt, raw s_barrier)
+//   k_conv_gbig    LDS-DMA gather for 1x1 and strided 3x3 (64- or 32-channel K-steps), optionally with the
+//                  "upsample2x + concat" source folded in (rva_conv1x1_upcat_f16)
+//   k_conv3_patch  resident weights + input patch staged once per output tile, for the small-channel layers
+//   k_stem         3x3 stride-2 conv on the planar fp16 tensor K1 writes (Cin = 3), bias + SiLU, NHWC out
+//   k_sppf_pool3 / k_maxpool5 / k_upsample2 / k_head3 / k_head   SPPF pooling, FPN upsample, DFL + dist2bbox + sigmoid
 //
 // Numerics: fp16 operands, fp32 accumulation and epilogue, one rounding to fp16 per layer output
 // (PyTorch rounds after conv, after bias and after SiLU); the engine is therefore checked against the
