@@ -1575,16 +1575,16 @@ struct S2Args {
     int B, H, W, Ho, Wo, Cout, CoutPad, act, tiles_x, tiles_y, total;
 };
 
-template <int STRIDE, int CIN, int CO, int NWV, int NBUF>
+template <int STRIDE, int CIN, int CO, int NWV, int NBUF, int RPW = 1>
 __global__ void __launch_bounds__(NWV * 64) k_conv3_patch(S2Args a)
 {
-    // output tile = NWV rows x 32 pixels (one wave per row); STRIDE 2: patch (2*NWV+1) x 65 as two column-parity planes,
+    // output tile = NWV*RPW rows x 32 pixels (RPW rows per wave: RPW = 2 halves the LDS reads per MFMA); STRIDE 2: patch (2*NWV+1) x 65 as two column-parity planes,
     // LDS row = (py*2 + (px & 1)) * 33 + (px >> 1);  STRIDE 1: patch (NWV+2) x 34, LDS row = py * 34 + px.
     // CIN 32: 64-byte rows (swz32), 16 rows per 1 KiB piece;  CIN 64: 128-byte rows (chunk ^ (row & 7)), 8 rows per piece.
     // NBUF 2: the next tile's patch is fetched under this tile's MFMAs and epilogue (one block per CU);  NBUF 1: one
     // patch buffer, several blocks per CU overlap each other instead.
     static_assert(CIN == 32 || CIN == 64, "input channels");
-    constexpr int TH = NWV, TW = 32, NT = NWV * 64;
+    constexpr int TH = NWV * RPW, TW = 32, NT = NWV * 64, FMW = 2 * RPW;
     constexpr int PH = STRIDE == 2 ? 2 * TH + 1 : TH + 2;
     constexpr int CW = STRIDE == 2 ? TW + 1 : TW + 2;                      // columns per (parity) plane
     constexpr int PROWS = STRIDE == 2 ? PH * 2 * CW : PH * CW;
@@ -1672,12 +1672,12 @@ __global__ void __launch_bounds__(NWV * 64) k_conv3_patch(S2Args a)
         const __half *patch = patch0 + (size_t)pb * PPIECES * 512;
         __half *stage = patch0 + (size_t)pb * PPIECES * 512;       // [TH*TW][SROW], once the patch is dead
         const int b = t / tiles_img, r2 = t - b * tiles_img, ty = r2 / a.tiles_x, tx = r2 - ty * a.tiles_x;
-        const int oy = ty * TH + wv;
-        // tap validity of this lane's two pixels (bit = dy * 3 + dx)
-        int vm[2];
+        // tap validity of this lane's pixels (bit = dy * 3 + dx); fragment j = row (j >> 1) of this wave, half (j & 1)
+        int vm[FMW];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int ox = tx * TW + 16 * j + (lane & 15);
+        for (int j = 0; j < FMW; ++j) {
+            const int oy = ty * TH + wv * RPW + (j >> 1);
+            const int ox = tx * TW + 16 * (j & 1) + (lane & 15);
             int m = 0;
             if (oy < a.Ho && ox < a.Wo) {
 #pragma unroll
@@ -1686,28 +1686,30 @@ __global__ void __launch_bounds__(NWV * 64) k_conv3_patch(S2Args a)
             }
             vm[j] = m;
         }
-        f4 acc[FN][2];
+        f4 acc[FN][FMW];
 #pragma unroll
         for (int i = 0; i < FN; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < FMW; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int tp = 0; tp < 9; ++tp) {
             const int dy = tp / 3, dx = tp % 3;
-            const int rb = (STRIDE == 2 ? ((2 * wv + dy) * 2 + (dx & 1)) * CW + (dx >> 1) : (wv + dy) * CW + dx) + (lane & 15);
+            // LDS row of this lane's pixel in wave-row r: STRIDE 2 -> patch row 2*(wv*RPW + r) + dy, parity plane dx & 1
+            const int rb = (STRIDE == 2 ? ((2 * wv * RPW + dy) * 2 + (dx & 1)) * CW + (dx >> 1) : (wv * RPW + dy) * CW + dx) + (lane & 15);
+            constexpr int ROWSTEP = STRIDE == 2 ? 4 * CW : CW;      // LDS rows between consecutive output rows
 #pragma unroll
             for (int ks = 0; ks < KCH; ++ks) {
-                h8 bf[2];
+                h8 bf[FMW];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    bf[j] = *reinterpret_cast<const h8 *>(patch + lds_off(rb + 16 * j, ks * 4 + (lane >> 4)));
+                for (int j = 0; j < FMW; ++j) {
+                    bf[j] = *reinterpret_cast<const h8 *>(patch + lds_off(rb + (j >> 1) * ROWSTEP + 16 * (j & 1), ks * 4 + (lane >> 4)));
                     if (!((vm[j] >> tp) & 1)) bf[j] = hz;
                 }
 #pragma unroll
                 for (int i = 0; i < FN; ++i) {
                     const h8 af = *reinterpret_cast<const h8 *>(wl + lds_off(tp * CO + 16 * i + (lane & 15), ks * 4 + (lane >> 4)));
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < FMW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[j], acc[i][j], 0, 0, 0);
                 }
             }
         }
@@ -1720,10 +1722,10 @@ __global__ void __launch_bounds__(NWV * 64) k_conv3_patch(S2Args a)
             const int co = 16 * i + (lane >> 4) * 4;
             const float4 bv = bvs[i];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < FMW; ++j) {
                 float v0 = acc[i][j][0] + bv.x, v1 = acc[i][j][1] + bv.y, v2 = acc[i][j][2] + bv.z, v3 = acc[i][j][3] + bv.w;
                 if (a.act) { v0 = silu_f(v0); v1 = silu_f(v1); v2 = silu_f(v2); v3 = silu_f(v3); }
-                const int px = wv * TW + 16 * j + (lane & 15);
+                const int px = (wv * RPW + (j >> 1)) * TW + 16 * (j & 1) + (lane & 15);
                 __half2 lo = __floats2half2_rn(v0, v1), hi = __floats2half2_rn(v2, v3);
                 uint2 pk;
                 pk.x = *reinterpret_cast<uint32_t *>(&lo);
@@ -1760,30 +1762,30 @@ __global__ void __launch_bounds__(NWV * 64) k_conv3_patch(S2Args a)
     }
 }
 
-template <int STRIDE, int CIN, int CO, int NWV, int NBUF>
+template <int STRIDE, int CIN, int CO, int NWV, int NBUF, int RPW = 1>
 hipError_t launch_patch(S2Args &g, int num_cus, hipStream_t s)
 {
-    constexpr int RPP = 512 / CIN;
-    constexpr int PROWS = STRIDE == 2 ? (2 * NWV + 1) * 2 * 33 : (NWV + 2) * 34;
+    constexpr int RPP = 512 / CIN, TH = NWV * RPW;
+    constexpr int PROWS = STRIDE == 2 ? (2 * TH + 1) * 2 * 33 : (TH + 2) * 34;
     constexpr size_t smem = (size_t)(9 * CO / RPP + NBUF * ((PROWS + RPP - 1) / RPP)) * 1024;
     static_assert(smem <= 160 * 1024, "LDS budget");   // 163,840 B per CU
     constexpr int per_cu = smem <= 32 * 1024 ? 4 : smem <= 53 * 1024 ? 3 : smem <= 80 * 1024 ? 2 : 1;
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_conv3_patch<STRIDE, CIN, CO, NWV, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipError_t e = hipFuncSetAttribute((const void *)k_conv3_patch<STRIDE, CIN, CO, NWV, NBUF, RPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
         attr = true;
     }
-    g.tiles_x = rva_ceil_div(g.Wo, 32); g.tiles_y = rva_ceil_div(g.Ho, NWV);
+    g.tiles_x = rva_ceil_div(g.Wo, 32); g.tiles_y = rva_ceil_div(g.Ho, TH);
     g.total = g.tiles_x * g.tiles_y * g.B;
     const int grid = g.total < per_cu * num_cus ? g.total : per_cu * num_cus;
-    k_conv3_patch<STRIDE, CIN, CO, NWV, NBUF><<<grid, NWV * 64, smem, s>>>(g);
+    k_conv3_patch<STRIDE, CIN, CO, NWV, NBUF, RPW><<<grid, NWV * 64, smem, s>>>(g);
     return hipGetLastError();
 }
 
 }  // namespace
 
-#define RVA_CONV_VARIANTS 49
+#define RVA_CONV_VARIANTS 51
 
 extern "C" {
 #ifdef RVA_ROW_STAMPS
@@ -1805,7 +1807,7 @@ int rva_dbg_read_stamps(unsigned long long *host) { return (int)hipMemcpyFromSym
 //   43..45 patch kernels for Cin = 32 (weights resident, input patch staged once per tile): 3x3 stride 2 with Cout <= 64;
 //          3x3 stride 1 with Cout <= 32, 4- and 8-row tiles
 //   46..49 patch kernels for 3x3 stride 1, Cin = 64, Cout <= 64 (double-buffered 4-row tile, 8-row tile, 4-row tile,
-//          double-buffered 8-row tile)
+//          double-buffered 8-row tile, and two forms with two output rows per wave)
 int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *weights, const float *bias, void *out,
                           int ldo, const void *residual, int ldr, int batch, int H, int W, int Cin, int Cout, int ksize,
                           int stride, int act, int variant, rva_stream_t stream_);
@@ -1874,6 +1876,8 @@ int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *wei
             else if (variant == 47) ev = launch_patch<1, 64, 64, 8, 1>(g, num_cus, s);    // 116 KB, eight waves, one buffer
             else if (variant == 48) ev = launch_patch<1, 64, 64, 4, 1>(g, num_cus, s);    // 98 KB
             else if (variant == 49) ev = launch_patch<1, 64, 64, 8, 2>(g, num_cus, s);    // 158 KB: eight waves, two patch buffers
+            else if (variant == 50) ev = launch_patch<1, 64, 64, 4, 2, 2>(g, num_cus, s); // 158 KB: four waves x two rows, two buffers
+            else if (variant == 51) ev = launch_patch<1, 64, 64, 8, 1, 2>(g, num_cus, s); // 149 KB: 16-row tile, eight waves x two rows
         }
         if (ev == hipSuccess) return RVA_OK;
         (void)hipGetLastError();

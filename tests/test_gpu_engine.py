@@ -188,9 +188,9 @@ def test_upcat_conv_matches_torch(shape):
 @pytest.mark.parametrize("shape", [(2, 21, 18, 64, 43), (1, 160, 160, 64, 43), (3, 33, 71, 32, 43), (2, 8, 64, 64, 43),
                                    (2, 21, 18, 32, 44), (1, 160, 160, 32, 45), (3, 33, 71, 32, 45), (2, 7, 64, 16, 44),
                                    (2, 21, 18, 64, 46), (1, 80, 80, 64, 46), (3, 33, 71, 64, 47), (2, 7, 64, 32, 48), (4, 40, 40, 64, 48),
-                                   (2, 80, 80, 64, 49), (3, 19, 45, 64, 49)])
+                                   (2, 80, 80, 64, 49), (3, 19, 45, 64, 49), (2, 80, 80, 64, 50), (3, 19, 45, 32, 50), (2, 80, 80, 64, 51), (3, 19, 45, 64, 51)])
 def test_patch_kernels_match_torch(shape):
-    """Variants 43-49: the resident-weight patch kernels (Cin = 32: 3x3 stride 2 -> Cout <= 64, stride 1 -> Cout <= 32; Cin = 64: stride 1 -> Cout <= 64),
+    """Variants 43-51: the resident-weight patch kernels (Cin = 32: 3x3 stride 2 -> Cout <= 64, stride 1 -> Cout <= 32; Cin = 64: stride 1 -> Cout <= 64),
     odd sizes, partial tiles, residual on the stride-1 form, an output slice with a row stride."""
     B, H, W, Cout, variant = shape
     stride = 2 if variant == 43 else 1
