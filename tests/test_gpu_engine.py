@@ -217,3 +217,27 @@ def test_patch_kernels_match_torch(shape):
     err = (out[..., 8:].float() - want).abs().max().item()
     assert err < 2e-2 + 2e-3 * want.abs().max().item(), err
     assert torch.all(out[..., :8] == 7.0)
+
+
+def test_fused_plan_at_bench_size_matches_torch_module():
+    """The benchmark configuration itself (YOLOv8s, batch 32, 640x640): at this size the autotuner picks the large-tile
+    LDS-DMA and patch kernels for most layers, so this validates the exact kernels bench.py times.  The reference side
+    runs in chunks of 8 frames (fp32 through MIOpen)."""
+    net = build_detector_net("s", seed=0)
+    ref = copy.deepcopy(net).fuse().float().cuda()
+    eng = FusedYoloV8(copy.deepcopy(net), 32)
+    picked = {v for _, v, _ in eng.tuning}
+    assert any(v >= 21 for v in picked), picked                      # LDS-DMA kernels are in use at this size
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.rand((32, 3, 640, 640), device="cuda", generator=g).half()
+    with torch.inference_mode():
+        got = eng(x).float()
+        want = torch.cat([ref(x[i:i + 8].float()) for i in range(0, 32, 8)])
+    torch.cuda.synchronize()
+    assert got.shape == want.shape == (32, 84, 8400) and torch.isfinite(got).all()
+    assert (got[:, :4] - want[:, :4]).abs().max() < 2.0              # pixels
+    assert (got[:, 4:] - want[:, 4:]).abs().max() < 2e-2             # class probabilities
+    assert (got[:, :4] - want[:, :4]).abs().mean() < 0.2
+    # frames are independent: the plan gives the same answer for a frame wherever it sits in the batch
+    y = eng(torch.roll(x, 5, 0)).float()
+    assert torch.equal(torch.roll(y, -5, 0), got)
