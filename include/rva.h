@@ -262,6 +262,13 @@ int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *wei
 int rva_conv1x1_upcat_f16(rva_ctx *ctx, const void *low, int ld_low, int c_low, const void *skip, int ld_skip,
                           int c_skip, const void *weights, const float *bias, void *out, int ldo, int batch,
                           int H, int W, int Cout, int act, int variant, rva_stream_t stream);
+/* Last 1x1 convolution of a detect-head branch fused with the head decode: mode 1 = box branch (Cout = 64 DFL logits ->
+ * expectation + dist2bbox, rows 0..3 of out), mode 2 = class branch (Cout = nc logits -> sigmoid, rows 4..4+nc), written
+ * straight into out[batch, 4+nc, anchors_total] at anchor_offset -- the logits never reach HBM.  Same arithmetic and
+ * rounding points as rva_conv2d_nhwc_f16 followed by rva_yolo_head_f16 (bit-identical).  Cin % 64 == 0; variant 0 or 33..39. */
+int rva_conv1x1_head_f16(rva_ctx *ctx, const void *in, int ldi, const void *weights, const float *bias, int batch,
+                         int H, int W, int Cin, int Cout, int mode, void *out, int nc, int anchors_total,
+                         int anchor_offset, float stride_px, int variant, rva_stream_t stream);
 int rva_stem_conv_f16(rva_ctx *ctx, const void *in_planar, const void *weights, const float *bias,
                       void *out, int ldo, int batch, int H, int W, int Cout, rva_stream_t stream);
 /* SPPF's three chained 5x5/1 max pools in one launch: out1 = pool5(in), out2 = pool5(out1) = pool9(in),

@@ -49,6 +49,8 @@ struct ConvArgs {
     __half *out; int ldo;
     const __half *res; int ldr;
     int CoutPad;
+    // k_conv_gbig<..., HEAD>: the detect head's last 1x1 convolutions decode straight into out[B, 4+nc, A]
+    __half *hout; int hmode, hnc, hA, ha0, hW, hHW; float hstride;   // hmode 1 = box branch (DFL + dist2bbox), 2 = class branch (sigmoid)
     const __half *in2; int ldi2, c_split;   // k_conv_gbig<..., UP>: `in` = low-res tensor (nearest 2x upsampled on the fly,
                                             // channels [0, c_split)), `in2` = full-res tensor (channels [c_split, Cin))
     int H, W, Cin, CinPad, Ho, Wo, Cout, stride, M, act, n_tiles, m_tiles;   // CinPad = Cin rounded up to 32 (weight rows are zero-padded)
@@ -1346,7 +1348,7 @@ hipError_t launch_big(BigArgs &a, hipStream_t s)
 // uses 64-byte rows with the swz32 rotation instead, 16 rows per piece.  Every wave owns BM/64 activation pieces
 // and BN/64 weight pieces per step, so the vmcnt count is a compile-time constant.  Taps that fall outside the image
 // read a clamped address and are zeroed per lane in the B fragment (9-bit mask per pixel).  Needs Cin % 64 == 0.
-template <int BM, int BN, int WGM, int WGN, int NSLOT, int KS, int BK, bool UP = false>
+template <int BM, int BN, int WGM, int WGN, int NSLOT, int KS, int BK, bool UP = false, bool HEAD = false>
 __global__ void __launch_bounds__(512)
     __attribute__((amdgpu_waves_per_eu(NSLOT * (BM + BN) * BK * 2 <= 80 * 1024 ? 4 : 2))) k_conv_gbig(ConvArgs a)
 {
@@ -1511,6 +1513,56 @@ __global__ void __launch_bounds__(512)
         }
     }
     __syncthreads();
+    if constexpr (HEAD) {
+        // thread = pixel row of the staged tile (values rounded to fp16 exactly as the stand-alone path stores them);
+        // same operation order as head_anchor, so the result is bit-identical to conv -> k_head
+        for (int r = tid; r < BM; r += 512) {
+            const int m = P0 + r;
+            if (m >= a.M) continue;
+            const int b = m / a.hHW, i = m - b * a.hHW;
+            __half *o = a.hout + (size_t)b * (4 + a.hnc) * a.hA + a.ha0 + i;
+            const __half *row = stage + (size_t)r * SROW;
+            if (a.hmode == 1) {
+                float d[4];
+#pragma unroll
+                for (int sd = 0; sd < 4; ++sd) {
+                    float v[16], mx = -1e30f;
+                    const uint4 q0 = *reinterpret_cast<const uint4 *>(row + sd * 16), q1 = *reinterpret_cast<const uint4 *>(row + sd * 16 + 8);
+                    const __half2 *h0 = reinterpret_cast<const __half2 *>(&q0), *h1 = reinterpret_cast<const __half2 *>(&q1);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        float2 f = __half22float2(h0[t]); v[2 * t] = f.x; v[2 * t + 1] = f.y;
+                        f = __half22float2(h1[t]); v[8 + 2 * t] = f.x; v[9 + 2 * t] = f.y;
+                    }
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) mx = fmaxf(mx, v[t]);
+                    float se = 0.f, sw = 0.f;
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) { const float e = __expf(v[t] - mx); se += e; sw += e * (float)t; }
+                    d[sd] = sw / se;
+                }
+                const float ax = (float)(i % a.hW) + 0.5f, ay = (float)(i / a.hW) + 0.5f;
+                const float x1 = ax - d[0], y1 = ay - d[1], x2 = ax + d[2], y2 = ay + d[3];
+                o[0] = __float2half_rn((x1 + x2) * 0.5f * a.hstride);
+                o[(size_t)a.hA] = __float2half_rn((y1 + y2) * 0.5f * a.hstride);
+                o[(size_t)2 * a.hA] = __float2half_rn((x2 - x1) * a.hstride);
+                o[(size_t)3 * a.hA] = __float2half_rn((y2 - y1) * a.hstride);
+            } else {
+                const int cend = min(BN, a.Cout - n0);
+                for (int c = 0; c < cend; c += 8) {
+                    const uint4 q = *reinterpret_cast<const uint4 *>(row + c);
+                    const __half2 *hq = reinterpret_cast<const __half2 *>(&q);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const float2 f = __half22float2(hq[t]);
+                        o[(size_t)(4 + n0 + c + 2 * t) * a.hA] = __float2half_rn(__builtin_amdgcn_rcpf(1.0f + __expf(-f.x)));
+                        o[(size_t)(5 + n0 + c + 2 * t) * a.hA] = __float2half_rn(__builtin_amdgcn_rcpf(1.0f + __expf(-f.y)));
+                    }
+                }
+            }
+        }
+        return;
+    }
     constexpr int CPR = BN / 8;
 #pragma unroll 4
     for (int q = tid; q < BM * CPR; q += 512) {
@@ -1534,7 +1586,7 @@ __global__ void __launch_bounds__(512)
     }
 }
 
-template <int BM, int BN, int WGM, int WGN, int NSLOT, int KS, int BK, bool UP = false>
+template <int BM, int BN, int WGM, int WGN, int NSLOT, int KS, int BK, bool UP = false, bool HEAD = false>
 hipError_t launch_gbig1(ConvArgs &a, hipStream_t s)
 {
     constexpr size_t ring = (size_t)NSLOT * (BM + BN) * BK * 2;
@@ -1543,12 +1595,12 @@ hipError_t launch_gbig1(ConvArgs &a, hipStream_t s)
     static_assert(smem <= 160 * 1024, "LDS budget");
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_conv_gbig<BM, BN, WGM, WGN, NSLOT, KS, BK, UP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipError_t e = hipFuncSetAttribute((const void *)k_conv_gbig<BM, BN, WGM, WGN, NSLOT, KS, BK, UP, HEAD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
         attr = true;
     }
     a.n_tiles = rva_ceil_div(a.Cout, BN);
-    k_conv_gbig<BM, BN, WGM, WGN, NSLOT, KS, BK, UP><<<rva_ceil_div(a.M, BM) * a.n_tiles, 512, smem, s>>>(a);
+    k_conv_gbig<BM, BN, WGM, WGN, NSLOT, KS, BK, UP, HEAD><<<rva_ceil_div(a.M, BM) * a.n_tiles, 512, smem, s>>>(a);
     return hipGetLastError();
 }
 
@@ -2061,6 +2113,38 @@ int rva_conv1x1_upcat_f16(rva_ctx *ctx, const void *low, int ld_low, int c_low, 
     default: return rva_fail(ctx, RVA_ERR_ARG, "rva_conv1x1_upcat_f16: variant %d not applicable (0 or 33..39)", variant);
     }
     if (ev != hipSuccess) return rva_fail(ctx, RVA_ERR_HIP, "rva_conv1x1_upcat_f16: launch failed: %s", hipGetErrorString(ev));
+    return RVA_OK;
+}
+
+int rva_conv1x1_head_f16(rva_ctx *ctx, const void *in, int ldi, const void *weights, const float *bias, int batch, int H, int W,
+                         int Cin, int Cout, int mode, void *out, int nc, int anchors_total, int anchor_offset, float stride_px,
+                         int variant, rva_stream_t stream_)
+{
+    if (!ctx) return RVA_ERR_ARG;
+    if (!in || !weights || !bias || !out || batch <= 0 || H <= 0 || W <= 0 || Cin % 64 || Cout % 8 || ldi % 8 || nc % 8 ||
+        (mode != 1 && mode != 2) || (mode == 1 && Cout != 64) || (mode == 2 && Cout != nc) ||
+        ((uintptr_t)in | (uintptr_t)weights) % 16 || H > 2000 || W > 2000)
+        return rva_fail(ctx, RVA_ERR_ARG, "rva_conv1x1_head_f16: unsupported shape (Cin %% 64; box branch Cout = 64; class branch Cout = nc)");
+    ConvArgs a{};
+    a.in = (const __half *)in; a.ldi = ldi; a.w = (const __half *)weights; a.bias = bias; a.out = nullptr; a.ldo = 0;
+    a.H = H; a.W = W; a.Cin = Cin; a.CinPad = Cin; a.Cout = Cout; a.stride = 1; a.act = 0; a.Ho = H; a.Wo = W; a.M = batch * H * W;
+    a.CoutPad = rva_ceil_div(Cout, 64) * 64;
+    a.hout = (__half *)out; a.hmode = mode; a.hnc = nc; a.hA = anchors_total; a.ha0 = anchor_offset; a.hW = W; a.hHW = H * W;
+    a.hstride = stride_px;
+    hipStream_t s = (hipStream_t)stream_;
+    hipError_t ev;
+    switch (variant) {
+    case 33: ev = launch_gbig1<256, 128, 4, 2, 3, 1, 64, false, true>(a, s); break;
+    case 34: ev = launch_gbig1<128, 128, 2, 4, 3, 1, 64, false, true>(a, s); break;
+    case 35: ev = launch_gbig1<256, 64, 4, 2, 3, 1, 64, false, true>(a, s); break;
+    case 36: ev = launch_gbig1<128, 64, 2, 4, 3, 1, 64, false, true>(a, s); break;
+    case 0:
+    case 37: ev = launch_gbig1<128, 128, 2, 4, 2, 1, 64, false, true>(a, s); break;
+    case 38: ev = launch_gbig1<256, 64, 4, 2, 2, 1, 64, false, true>(a, s); break;
+    case 39: ev = launch_gbig1<192, 128, 4, 2, 2, 1, 64, false, true>(a, s); break;
+    default: return rva_fail(ctx, RVA_ERR_ARG, "rva_conv1x1_head_f16: variant %d not applicable (0 or 33..39)", variant);
+    }
+    if (ev != hipSuccess) return rva_fail(ctx, RVA_ERR_HIP, "rva_conv1x1_head_f16: launch failed: %s", hipGetErrorString(ev));
     return RVA_OK;
 }
 

@@ -140,6 +140,25 @@ class FusedYoloV8:
         self._steps.append(run)
         self._tunable.append((launch, state, f"up{low.ch}+{skip.ch}->{cout} k1s1 {h}x{w}"))
 
+    def _conv_head(self, conv, src: _View, mode: int, h: int, w: int, a0: int, stride: float):
+        """Last 1x1 convolution of a detect-head branch with the head decode as its epilogue (rva_conv1x1_head_f16):
+        mode 1 = box branch, mode 2 = class branch; writes rows of ``self.out`` at anchor offset ``a0``."""
+        wp, bp, cin, cout, k, st = self._conv_params(conv)
+        assert k == 1 and st == 1 and cin == src.ch
+        B, L, ctx = self.B, self.L, self.ctx
+        state = {"variant": 0}
+
+        def launch(stream, variant):
+            if variant and not 33 <= variant <= 39:
+                return N.RVA_ERR_ARG
+            return L.rva_conv1x1_head_f16(ctx.handle, src.ptr, src.ld, _p(wp), _p(bp), B, h, w, cin, cout, mode, _p(self.out), self.nc,
+                                          self.A, a0, C.c_float(stride), variant, stream)
+
+        def run(stream):
+            ctx.check(launch(stream, state["variant"]), "rva_conv1x1_head_f16")
+        self._steps.append(run)
+        self._tunable.append((launch, state, f"head{mode}:{cin}->{cout} k1s1 {h}x{w}"))
+
     def _c2f(self, mod: C2f, src, dst: _View, h: int, w: int):
         """``src``: a view, or a pair (low, skip) standing for cat([upsample2x(low), skip])."""
         c, n = mod.c, len(mod.m)
@@ -252,6 +271,10 @@ class FusedYoloV8:
         self.out = torch.empty((B, 4 + self.nc, A), dtype=torch.float16, device=self.dev)
         a0 = 0
         levels = []
+        # the last 1x1 convolution of each branch can decode straight into the result tensor (no logits in HBM, no head
+        # kernel) when its input width suits the LDS-DMA gather kernel
+        fuse_head = all(net.detect.box[l][2].in_channels % 64 == 0 and net.detect.cls[l][2].in_channels % 64 == 0 and
+                        net.detect.box[l][2].out_channels == 64 and net.detect.cls[l][2].out_channels == self.nc for l in range(3))
         for lvl, (feat, hh, ww, stride) in enumerate(((n3, h3, w3, 8.0), (m4, h4, w4, 16.0), (m5, h5, w5, 32.0))):
             box, cls = net.detect.box[lvl], net.detect.cls[lvl]
             m = B * hh * ww
@@ -266,10 +289,16 @@ class FusedYoloV8:
             k2 = _View(self._buf(m, cc), 0, cc)
             ko = _View(self._buf(m, self.nc), 0, self.nc)
             self._conv([box[0], cls[0]], feat, first, hh, ww)
-            self._conv(box[1], b1, b2, hh, ww); self._conv(box[2], b2, bo, hh, ww)
-            self._conv(cls[1], k1, k2, hh, ww); self._conv(cls[2], k2, ko, hh, ww)
+            if fuse_head:
+                self._conv(box[1], b1, b2, hh, ww); self._conv_head(box[2], b2, 1, hh, ww, a0, stride)
+                self._conv(cls[1], k1, k2, hh, ww); self._conv_head(cls[2], k2, 2, hh, ww, a0, stride)
+            else:
+                self._conv(box[1], b1, b2, hh, ww); self._conv(box[2], b2, bo, hh, ww)
+                self._conv(cls[1], k1, k2, hh, ww); self._conv(cls[2], k2, ko, hh, ww)
             levels.append((bo, ko, hh, ww, stride))
             a0 += hh * ww
+        if fuse_head:
+            return
         # DFL + dist2bbox + sigmoid of the three levels in one launch
         bp, _k1 = N.ptr_array([lv[0].ptr.value for lv in levels]); kp, _k2 = N.ptr_array([lv[1].ptr.value for lv in levels])
         lb, _k3 = N.i32_array([lv[0].ld for lv in levels]); lc, _k4 = N.i32_array([lv[1].ld for lv in levels])

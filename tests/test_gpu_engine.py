@@ -241,3 +241,40 @@ def test_fused_plan_at_bench_size_matches_torch_module():
     # frames are independent: the plan gives the same answer for a frame wherever it sits in the batch
     y = eng(torch.roll(x, 5, 0)).float()
     assert torch.equal(torch.roll(y, -5, 0), got)
+
+
+@pytest.mark.parametrize("mode,Cin,Cout", [(1, 64, 64), (2, 128, 80), (2, 192, 80)])
+def test_head_fused_conv_is_bit_identical_to_conv_then_head(mode, Cin, Cout):
+    """rva_conv1x1_head_f16 == rva_conv2d_nhwc_f16 (1x1, no activation) followed by rva_yolo_head_f16, bit for bit, for
+    every applicable variant (the decode runs on the fp16-rounded tile exactly as the stand-alone kernel reads it)."""
+    B, H, W, nc = 3, 20, 13, 80
+    A, a0, stride = H * W + 37, 21, 16.0
+    g = torch.Generator().manual_seed(11 + mode)
+    x = (torch.randn((B, H, W, Cin), generator=g) * 0.7).half().cuda()
+    w = (torch.randn((Cout, Cin), generator=g) / Cin ** 0.5 * 2).half()
+    b = torch.randn((Cout,), generator=g) * 0.3
+    L, ctx = N.lib(), ops.context()
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    cpad = L.rva_conv_cout_pad(Cout)
+    wp = torch.zeros((cpad, 1, Cin), dtype=torch.float16); wp[:Cout, 0] = w
+    bp = torch.zeros(cpad); bp[:Cout] = b
+    wp, bp = wp.cuda(), bp.cuda()
+    # reference path: conv -> logits in HBM -> head kernel (the other branch is fed zeros)
+    logits = torch.zeros((B, H, W, Cout), dtype=torch.float16, device="cuda")
+    ctx.check(L.rva_conv2d_nhwc_f16(ctx.handle, C.c_void_p(x.data_ptr()), Cin, C.c_void_p(wp.data_ptr()), C.c_void_p(bp.data_ptr()),
+                                    C.c_void_p(logits.data_ptr()), Cout, None, 0, B, H, W, Cin, Cout, 1, 1, 0, s))
+    other = torch.zeros((B, H, W, 64 if mode == 2 else nc), dtype=torch.float16, device="cuda")
+    want = torch.full((B, 4 + nc, A), -3.0, dtype=torch.float16, device="cuda")
+    box_t, cls_t = (logits, other) if mode == 1 else (other, logits)
+    ctx.check(L.rva_yolo_head_f16(ctx.handle, C.c_void_p(box_t.data_ptr()), 64, C.c_void_p(cls_t.data_ptr()), nc, C.c_void_p(want.data_ptr()),
+                                  B, H, W, nc, A, a0, C.c_float(stride), s))
+    rows = slice(0, 4) if mode == 1 else slice(4, 4 + nc)
+    for variant in [0] + list(range(33, 40)):
+        got = torch.full((B, 4 + nc, A), -3.0, dtype=torch.float16, device="cuda")
+        ctx.check(L.rva_conv1x1_head_f16(ctx.handle, C.c_void_p(x.data_ptr()), Cin, C.c_void_p(wp.data_ptr()), C.c_void_p(bp.data_ptr()),
+                                         B, H, W, Cin, Cout, mode, C.c_void_p(got.data_ptr()), nc, A, a0, C.c_float(stride), variant, s))
+        torch.cuda.synchronize()
+        assert torch.equal(got[:, rows, a0:a0 + H * W], want[:, rows, a0:a0 + H * W]), variant
+        untouched = torch.ones_like(got, dtype=torch.bool)
+        untouched[:, rows, a0:a0 + H * W] = False
+        assert torch.all(got[untouched] == -3.0), variant

@@ -16,6 +16,8 @@ rows = []
 for d, n in seen.items():
     v, us = t[d]
     tot += us * n
+    d0 = d
+    d = re.sub(r"^head[12]:", "", d)
     mu = re.match(r"up(\d+)\+(\d+)->(\d+) k1s1 (\d+)x(\d+)", d)
     if mu:      # fused upsample + concat source: the low-res part is read at quarter size
         cl, cs, cout, h, w = map(int, mu.groups())
