@@ -36,8 +36,8 @@ MFMA_PEAK_TFLOPS = 2500.0               # dense fp16
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--streams", type=int, default=32, help="streams per GPU")
     ap.add_argument("--model", default="s", choices=["n", "s", "m"])
     ap.add_argument("--width", type=int, default=1920)
