@@ -165,15 +165,42 @@ void rva_tracker_destroy(rva_tracker *trk);
 /* Detections straight from rva_postprocess_batch (device, float32, [batch, max_det] layout).
  * slot_of_stream: host int32[n_streams]; entry s = batch row holding stream s's detections this
  * tick, or -1 if stream s has no frame this tick (its table is untouched), or -2 for a skipped
- * frame (update(name, []) of pipeline.py:215: ages every track).
+ * frame (update(name, []) of pipeline.py:215: ages every track), or -3 when ANOTHER update launch of
+ * the same tick owns stream s (a tick with several detectors / frame geometries issues one launch per
+ * group; -3 leaves the stream's table and its new-track count alone).
  * filter_thr: filter_detections' threshold (pipeline.py:182), applied on the widened score. */
 int rva_tracker_update_f32(rva_tracker *trk, const int32_t *slot_of_stream, const float *boxes,
                            const float *scores, const int32_t *cls, const int32_t *counts, int max_det,
                            double filter_thr, rva_stream_t stream);
 
+/* The same update with the pre-detector gates of StreamWorker._process_packet decided ON THE DEVICE, so a gated
+ * tick needs no host round trip (the detector has then run on every delivered frame; a gated-out frame becomes a
+ * skipped frame here):
+ *   motion gate (pipeline.py:156-163, utils/frame_filter.py:26-40): motion_row[s] (host int32[n_streams]) = row of
+ *     the device array motion_counts (written by rva_motion_*_batch earlier on this stream) holding stream s's
+ *     changed-pixel count, or -1 when the stream has no motion gate; a count of -1 (first frame) always passes, else
+ *     the frame is processed iff count >= the stream's motion_min_count (rva_tracker_set_gates);
+ *   adaptive-fps gate (pipeline.py:107-116, 165-170) and _adjust_adaptive_state (:242-262): frame index, idle
+ *     frames and process_every live in HBM per stream and are advanced by this kernel with len(filtered) and
+ *     len(tracks) of the update.
+ * Streams whose slot is -2 are skipped by the caller's decision; their gate state advances like any other frame. */
+int rva_tracker_update_gated_f32(rva_tracker *trk, const int32_t *slot_of_stream, const float *boxes,
+                                 const float *scores, const int32_t *cls, const int32_t *counts, int max_det,
+                                 double filter_thr, const int32_t *motion_counts, const int32_t *motion_row,
+                                 rva_stream_t stream);
+
+/* Gate parameters per stream (host int32[n_streams] each; host-synchronous): adaptive_enabled = StreamConfig.adaptive_fps,
+ * max_process_every = max(1, int(round(target_fps / max(min_target_fps, 1)))), idle_tolerance =
+ * max(int(idle_frame_tolerance), 1) (pipeline.py:107-116); motion_min_count = smallest changed-pixel count c with
+ * float(c) / float(w * h) >= motion_threshold (0 when the stream has no motion gate).  reset_state != 0 also rewinds
+ * every stream's frame index / idle counter / process_every to their initial values. */
+int rva_tracker_set_gates(rva_tracker *trk, const int32_t *adaptive_enabled, const int32_t *max_process_every,
+                          const int32_t *idle_tolerance, const int32_t *motion_min_count, int reset_state);
+
 /* Detections supplied by the host API (IouTracker.update(stream_name, detections)): device arrays
  * double boxes[total][4], double conf[total], int64 cls[total]; stream s owns rows
- * [offsets[s], offsets[s+1]) when active[s] != 0 (host arrays, n_streams(+1) entries). */
+ * [offsets[s], offsets[s+1]) when active[s] == 1 (host arrays, n_streams(+1) entries); active[s] == 0: no
+ * update for the stream this tick; active[s] == 2: another update launch of this tick owns it (left alone). */
 int rva_tracker_update_f64(rva_tracker *trk, const int32_t *active, const int32_t *offsets,
                            const double *boxes, const double *conf, const int64_t *cls,
                            rva_stream_t stream);
@@ -219,6 +246,13 @@ int rva_tracker_snapshot_async(rva_tracker *trk, int slot, rva_stream_t stream);
 int rva_tracker_snapshot_fetch(rva_tracker *trk, int slot, int wait, int64_t *ids, int32_t *cls, int32_t *age,
                                int32_t *hits, double *conf, double *boxes, int32_t *last_det,
                                int32_t *counts);
+
+/* What rides along in a snapshot slot besides the tables (no wait: call after snapshot_fetch / the graph launch has
+ * completed): emitted[s] = len(filtered) of the stream's last update (pipeline.py:187), processed[s] = 1 processed /
+ * 0 skipped frame / -1 no frame, *flags = tracker flags (bit 0: a table overflowed `capacity`, detections dropped)
+ * | post-process flags << 8 (bit 8: more survivors than max_det, bit 9: more thresholded anchors than the sort holds).
+ * The reference is unbounded in all three places, so a caller must treat a non-zero value as an error. */
+int rva_tracker_snapshot_status(rva_tracker *trk, int slot, int32_t *emitted, int32_t *processed, int32_t *flags);
 
 /* Host-synchronous: next id the counter will hand out; flags bit 0 = a table overflowed `capacity`. */
 int rva_tracker_state(rva_tracker *trk, int64_t *next_id, int *flags, rva_stream_t stream);

@@ -258,12 +258,7 @@ hipError_t launch_conv(const ConvArgs &a, hipStream_t s)
 {
     if (a.CinPad % BK) return hipErrorInvalidValue;
     constexpr size_t smem = conv_smem<BN, WPX, KS, BK>();
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_conv_mfma<BN, WPX, KS, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return e;
-        attr = true;
-    }
+    if (hipError_t e = rva_func_smem((const void *)k_conv_mfma<BN, WPX, KS, BK>, smem); e != hipSuccess) return e;
     k_conv_mfma<BN, WPX, KS, BK><<<a.m_tiles * a.n_tiles, 256, smem, s>>>(a);
     return hipGetLastError();
 }
@@ -471,12 +466,7 @@ hipError_t launch_row(RowArgs &a, int batch, hipStream_t s)
     constexpr size_t op = (size_t)2 * ((((BM + 2) + 3) & ~3) + BN * 3) * 32 * 2;
     constexpr size_t st = (size_t)BM * (BN + 8) * 2;
     constexpr size_t smem = op > st ? op : st;
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_conv3_row<BN, WPX, PF2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return e;
-        attr = true;
-    }
+    if (hipError_t e = rva_func_smem((const void *)k_conv3_row<BN, WPX, PF2>, smem); e != hipSuccess) return e;
     a.tiles_per_img = rva_ceil_div(a.H * a.W, BM);
     k_conv3_row<BN, WPX, PF2><<<batch * a.tiles_per_img * a.n_tiles, 256, smem, s>>>(a);
     return hipGetLastError();
@@ -723,12 +713,7 @@ hipError_t launch_res(ResArgs &a, int batch, int num_cus, hipStream_t s)
     const size_t st = (size_t)BM * (BN + 8) * 2;
     const size_t smem = op > st ? op : st;
     if (smem > 160 * 1024) return hipErrorInvalidValue;
-    static size_t attr = 0;
-    if (smem > attr) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_conv_res<BN, WPX, KS, CK, NA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return e;
-        attr = smem;
-    }
+    if (hipError_t e = rva_func_smem((const void *)k_conv_res<BN, WPX, KS, CK, NA>, smem); e != hipSuccess) return e;
     // persistent grid: one block per CU, a multiple of n_tiles so a block keeps its weight columns
     int grid = num_cus - num_cus % a.n_tiles;
     if (grid <= 0) grid = a.n_tiles;
@@ -1328,12 +1313,7 @@ hipError_t launch_big(BigArgs &a, hipStream_t s)
     constexpr size_t smem = ring > st ? ring : st;
     static_assert(smem <= 160 * 1024, "LDS budget");
     if (a.Cin % 32 || a.CoutPad % 4) return hipErrorInvalidValue;
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_conv3_big<BM, BN, WGM, WGN, NSLOT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return e;
-        attr = true;
-    }
+    if (hipError_t e = rva_func_smem((const void *)k_conv3_big<BM, BN, WGM, WGN, NSLOT>, smem); e != hipSuccess) return e;
     a.n_tiles = rva_ceil_div(a.Cout, BN);
     k_conv3_big<BM, BN, WGM, WGN, NSLOT><<<rva_ceil_div(a.M, BM) * a.n_tiles, 512, smem, s>>>(a);
     return hipGetLastError();
@@ -1593,12 +1573,7 @@ hipError_t launch_gbig1(ConvArgs &a, hipStream_t s)
     constexpr size_t st = (size_t)BM * (BN + 8) * 2;
     constexpr size_t smem = ring > st ? ring : st;
     static_assert(smem <= 160 * 1024, "LDS budget");
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_conv_gbig<BM, BN, WGM, WGN, NSLOT, KS, BK, UP, HEAD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return e;
-        attr = true;
-    }
+    if (hipError_t e = rva_func_smem((const void *)k_conv_gbig<BM, BN, WGM, WGN, NSLOT, KS, BK, UP, HEAD>, smem); e != hipSuccess) return e;
     a.n_tiles = rva_ceil_div(a.Cout, BN);
     k_conv_gbig<BM, BN, WGM, WGN, NSLOT, KS, BK, UP, HEAD><<<rva_ceil_div(a.M, BM) * a.n_tiles, 512, smem, s>>>(a);
     return hipGetLastError();
@@ -1822,12 +1797,7 @@ hipError_t launch_patch(S2Args &g, int num_cus, hipStream_t s)
     constexpr size_t smem = (size_t)(9 * CO / RPP + NBUF * ((PROWS + RPP - 1) / RPP)) * 1024;
     static_assert(smem <= 160 * 1024, "LDS budget");   // 163,840 B per CU
     constexpr int per_cu = smem <= 32 * 1024 ? 4 : smem <= 53 * 1024 ? 3 : smem <= 80 * 1024 ? 2 : 1;
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_conv3_patch<STRIDE, CIN, CO, NWV, NBUF, RPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return e;
-        attr = true;
-    }
+    if (hipError_t e = rva_func_smem((const void *)k_conv3_patch<STRIDE, CIN, CO, NWV, NBUF, RPW>, smem); e != hipSuccess) return e;
     g.tiles_x = rva_ceil_div(g.Wo, 32); g.tiles_y = rva_ceil_div(g.Ho, TH);
     g.total = g.tiles_x * g.tiles_y * g.B;
     const int grid = g.total < per_cu * num_cus ? g.total : per_cu * num_cus;
@@ -1893,12 +1863,12 @@ int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *wei
     // tile choice: weights are padded to a multiple of 64 output channels by the caller (rva_conv_cout_pad)
     const int cpad = rva_ceil_div(Cout, 64) * 64;
     const bool bn128 = cpad % 128 == 0;
-    static int num_cus = 0;
-    if (!num_cus) {
+    if (!ctx->num_cus) {
         hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess) num_cus = prop.multiProcessorCount;
-        if (num_cus <= 0) num_cus = 256;
+        if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess) ctx->num_cus = prop.multiProcessorCount;
+        if (ctx->num_cus <= 0) ctx->num_cus = 256;
     }
+    const int num_cus = ctx->num_cus;
     if (variant == 0) {
         // heuristic (callers that do not autotune): the LDS-DMA kernels wherever their channel constraints hold,
         // tile picked from the autotune tables of the YOLOv8 layers (tools/show_tuning.py)
@@ -2185,11 +2155,7 @@ int rva_sppf_pool3_nhwc_f16(rva_ctx *ctx, const void *in, int ldi, void *out1, v
         return rva_fail(ctx, RVA_ERR_ARG, "rva_sppf_pool3_nhwc_f16: bad argument");
     const size_t smem = (size_t)H * W * 16 * 4;
     if (smem > 150 * 1024) return rva_fail(ctx, RVA_ERR_ARG, "rva_sppf_pool3_nhwc_f16: H*W too large for one LDS tile (use rva_maxpool5_nhwc_f16 x3)");
-    static bool attr = false;
-    if (!attr) {
-        RVA_HIP(ctx, hipFuncSetAttribute((const void *)k_sppf_pool3, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        attr = true;
-    }
+    RVA_HIP(ctx, rva_func_smem((const void *)k_sppf_pool3, 150 * 1024));
     k_sppf_pool3<<<batch * (C / 8), 256, smem, (hipStream_t)stream_>>>((const __half *)in, ldi, (__half *)out1, (__half *)out2,
                                                                        (__half *)out3, ldo, H, W, C);
     RVA_HIP(ctx, hipGetLastError());

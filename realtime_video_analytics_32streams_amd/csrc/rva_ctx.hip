@@ -3,8 +3,27 @@
 
 #include <cmath>
 #include <cstring>
+#include <mutex>
+#include <utility>
 
 #include "rva_internal.h"
+
+hipError_t rva_func_smem(const void *fn, size_t bytes)
+{
+    static std::mutex mu;
+    static std::map<std::pair<int, const void *>, size_t> done;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> g(mu);
+    size_t &have = done[std::make_pair(dev, fn)];
+    if (bytes > have) {
+        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return e;
+        have = bytes;
+    }
+    return hipSuccess;
+}
 
 extern "C" {
 

@@ -39,6 +39,8 @@ struct rva_ctx {
     std::map<uint64_t, rva_resize_table> taps_x, taps_y;
     // one-shot profiling events for the next K1 (integer-ratio) launch: rva_profile_next_preprocess
     hipEvent_t k1_start = nullptr, k1_stop = nullptr;
+    int k1_px = -1;               // RVA_K1_PX tuning switch, read once per context
+    int num_cus = 0;              // multiProcessorCount of ctx->device (persistent-grid sizing)
 };
 
 inline int rva_fail(rva_ctx *ctx, int code, const char *fmt, ...)
@@ -64,3 +66,9 @@ inline int rva_fail(rva_ctx *ctx, int code, const char *fmt, ...)
 int rva_get_taps(rva_ctx *ctx, int src, int dst, bool is_x, rva_resize_table *out);
 
 static inline int rva_ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// Raise a kernel's dynamic-LDS limit (hipFuncAttributeMaxDynamicSharedMemorySize) to at least `bytes` on the CURRENT
+// device.  The attribute belongs to the (device, function) pair, so the bookkeeping is keyed by both: a second context
+// on another device of the same process gets its own call (a process-global `static bool` would skip it).  Must not be
+// reached for the first time inside a stream capture: callers run one eager launch of every kernel before capturing.
+hipError_t rva_func_smem(const void *fn, size_t bytes);

@@ -328,11 +328,7 @@ extern "C" int rva_postprocess_batch(rva_ctx *ctx, const void *raw, int raw_dtyp
     while (kcap < A && kcap < 16384) kcap <<= 1;
     const int nwords = rva_ceil_div(A, 32);
     const size_t smem = (((size_t)kcap * 9 + 64 * 16 + 16 + 15) & ~(size_t)15) + (size_t)nwords * 4 + 64;
-    static size_t smem_set = 0;
-    if (smem > smem_set) {
-        RVA_HIP(ctx, hipFuncSetAttribute((const void *)k3_nms, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        smem_set = smem;
-    }
+    RVA_HIP(ctx, rva_func_smem((const void *)k3_nms, smem));
 
     for (int b0 = 0; b0 < batch; b0 += RVA_MAX_BATCH) {
         const int nb = batch - b0 < RVA_MAX_BATCH ? batch - b0 : RVA_MAX_BATCH;

@@ -362,8 +362,8 @@ int preprocess_common(rva_ctx *ctx, bool nv12, int mode, const void *const *p0, 
                           (dst_w % 8 == 0) && (m.new_w % 8 == 0) && (m.pad_left % 8 == 0);
     if (ratio_ok) {
         // 16 pixels per lane (16-byte loads) when the geometry is 16-aligned and every surface 16-byte aligned
-        static int px_env = -1;
-        if (px_env < 0) { const char *e = getenv("RVA_K1_PX"); px_env = e ? atoi(e) : 0; }
+        if (ctx->k1_px < 0) { const char *e = getenv("RVA_K1_PX"); ctx->k1_px = e ? atoi(e) : 0; }
+        const int px_env = ctx->k1_px;
         bool aligned16 = true;
         for (int i = 0; i < n; ++i)
             aligned16 = aligned16 && ((uintptr_t)p0[i] % 16 == 0) && ((uintptr_t)p1[i] % 16 == 0) && pitches[i] % 16 == 0;

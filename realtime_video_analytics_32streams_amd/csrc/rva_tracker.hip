@@ -41,6 +41,11 @@ struct rva_tracker {
     int32_t *d_offs = nullptr;    // [S+1]
     int32_t *d_gidx = nullptr;    // [S]
     double *d_bscale = nullptr;   // [S] box scale of _rescale_detections (1.0 = no downsample)
+    // pre-detector gates decided on the device (pipeline.py:156-170, 242-262), see rva_tracker_set_gates
+    int32_t *gate_cfg = nullptr;    // [S][4] adaptive enabled, max_process_every, idle_tolerance, motion minimum count
+    int32_t *gate_state = nullptr;  // [S][4] frame_index, idle_frames, process_every, -
+    int32_t *emitted = nullptr;     // [S] len(filtered) of the last update (pipeline.py:187)
+    int32_t *processed = nullptr;   // [S] last update: 1 processed, 0 skipped frame, -1 no frame
     // pinned host staging
     int32_t *h_slot = nullptr, *h_offs = nullptr;
     void *h_read[2] = {nullptr, nullptr};   // pinned snapshot slots
@@ -58,8 +63,12 @@ struct K4Args {
     int cap, max_age, min_hits;
     double min_iou;
     const int32_t *slot;  // f64 path: device [S] active flags (staged); f32 path: unused
-    int32_t kslot[RVA_MAX_TRACKER_STREAMS];  // f32 path: batch row, -1 idle, -2 skipped frame (kernarg-resident:
-                                             // no staging buffer to race with, and graph-capturable)
+    int16_t kslot[RVA_MAX_TRACKER_STREAMS];  // f32 path: batch row, -1 no frame, -2 skipped frame, -3 not part of this
+                                             // launch (kernarg-resident: no staging buffer to race with, graph-capturable)
+    int16_t mrow[RVA_MAX_TRACKER_STREAMS];   // f32 path, device gates: row of motion_cnt holding the stream's K5 count, -1 = no gate
+    const int32_t *motion_cnt;               // K5 counts (-1 = first frame of the stream: always processed)
+    int32_t *gate_cfg, *gate_state;          // null: gates are decided by the host (kslot -2)
+    int32_t *emitted, *processed;
     // f32 source (post-process outputs)
     const float4 *boxes32; const float *scores32; const int32_t *cls32; const int32_t *counts32; int max_det;
     const double *bscale;   // per-stream multiplier applied to the widened box (pipeline.py:237)
@@ -93,10 +102,27 @@ template <bool F64SRC>
 __global__ void __launch_bounds__(64) k4_update(K4Args a)
 {
     const int s = blockIdx.x, lane = threadIdx.x;
-    const int slot = F64SRC ? a.slot[s] : a.kslot[s];
+    const int slot = F64SRC ? a.slot[s] : (int)a.kslot[s];
+    if (F64SRC ? slot == 2 : slot == -3) return;   // another launch of this tick owns the stream: leave everything alone
     if (F64SRC ? slot == 0 : slot == -1) {  // stream not updated this tick
-        if (lane == 0) a.n_new[s] = 0;
+        if (lane == 0) { a.n_new[s] = 0; a.processed[s] = -1; a.emitted[s] = 0; }
         return;
+    }
+    // pre-detector gates on the device (f32 path): motion gate first (utils/frame_filter.py:26-40 via the K5 count, first
+    // frame always passes), then the adaptive-fps gate (pipeline.py:165-170); a frame that fails either is a skipped frame
+    bool process = F64SRC ? true : slot >= 0;
+    int g_fi = 0, g_idle = 0, g_pe = 1, g_on = 0, g_maxpe = 1, g_tol = 0;
+    if (!F64SRC && a.gate_cfg) {
+        const int32_t *cfg = a.gate_cfg + 4 * s;
+        const int32_t *st = a.gate_state + 4 * s;
+        g_on = cfg[0]; g_maxpe = cfg[1]; g_tol = cfg[2];
+        g_fi = st[0] + 1; g_idle = st[1]; g_pe = st[2];            // pipeline.py:144: the frame index advances for every frame
+        const int mr = a.mrow[s];
+        if (mr >= 0) {
+            const int cnt = a.motion_cnt[mr];
+            if (cnt >= 0 && cnt < cfg[3]) process = false;         // ratio < motion_threshold (host turned it into a count)
+        }
+        if (g_on && g_pe > 1 && (g_fi - 1) % g_pe != 0) process = false;
     }
     const int cap = a.cap;
     double *l_box = (double *)k4_smem;                 // [4][cap]  (component-major: conflict-free)
@@ -123,8 +149,8 @@ __global__ void __launch_bounds__(64) k4_update(K4Args a)
 
     int D = 0, d0 = 0;
     if (F64SRC) { d0 = a.offs[s]; D = a.offs[s + 1] - d0; }
-    else if (slot >= 0) D = a.counts32[slot];
-    int created = 0;
+    else if (process) D = a.counts32[slot];
+    int created = 0, n_emit = 0;
     bool overflow = false;
     for (int d = 0; d < D; ++d) {
         double b0, b1, b2, b3, dconf;
@@ -144,6 +170,7 @@ __global__ void __launch_bounds__(64) k4_update(K4Args a)
             dcls = a.cls32[o];
             if (!(dconf >= a.filter_thr)) continue;  // filter_detections, pipeline.py:182 (wave-uniform)
         }
+        ++n_emit;
         double best = 0.0;  // tracker.py:100
         int bi = INT_MAX;
         for (int k = lane; k < n; k += 64) {
@@ -195,7 +222,17 @@ __global__ void __launch_bounds__(64) k4_update(K4Args a)
     if (lane == 0) {
         a.n_tracks[s] = base;
         a.n_new[s] = created;
+        a.emitted[s] = n_emit;
+        a.processed[s] = process ? 1 : 0;
         if (overflow) atomicOr(a.flags, 1);
+        if (!F64SRC && a.gate_cfg) {                 // _adjust_adaptive_state(len(filtered), len(tracks)), pipeline.py:242-262
+            if (g_on) {
+                if (n_emit > 0 || base > 0) { g_idle = 0; g_pe = 1; }
+                else { ++g_idle; if (g_idle >= g_tol) g_pe = g_maxpe > 1 ? g_maxpe : 1; }
+            }
+            int32_t *st = a.gate_state + 4 * s;
+            st[0] = g_fi; st[1] = g_idle; st[2] = g_pe;
+        }
     }
 }
 
@@ -245,6 +282,7 @@ int launch_update(rva_tracker *t, K4Args &a, bool f64, hipStream_t stream)
 {
     a.id = t->id; a.box = t->box; a.conf = t->conf; a.cls = t->cls; a.age = t->age; a.hits = t->hits; a.last_det = t->last_det;
     a.n_tracks = t->n_tracks; a.n_new = t->n_new; a.flags = t->flags;
+    a.emitted = t->emitted; a.processed = t->processed;
     a.cap = t->cap; a.max_age = t->max_age; a.min_hits = t->min_hits; a.min_iou = t->min_iou;
     const size_t smem = k4_smem_bytes(t->cap);
     if (f64) k4_update<true><<<t->n_streams, 64, smem, stream>>>(a);
@@ -265,8 +303,8 @@ int rva_tracker_create(rva_ctx *ctx, int n_streams, int capacity, int max_age, d
     const size_t smem = k4_smem_bytes(capacity);
     if (smem > 160 * 1024) return rva_fail(ctx, RVA_ERR_CAPACITY, "tracker capacity %d needs %zu B of LDS (max 160 KiB)", capacity, smem);
     RVA_HIP(ctx, hipSetDevice(ctx->device));
-    RVA_HIP(ctx, hipFuncSetAttribute((const void *)k4_update<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    RVA_HIP(ctx, hipFuncSetAttribute((const void *)k4_update<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    RVA_HIP(ctx, rva_func_smem((const void *)k4_update<true>, smem));
+    RVA_HIP(ctx, rva_func_smem((const void *)k4_update<false>, smem));
     rva_tracker *t = new rva_tracker();
     t->ctx = ctx; t->n_streams = n_streams; t->cap = capacity; t->max_age = max_age; t->min_hits = min_hits;
     t->min_iou = max_iou_distance;
@@ -292,10 +330,18 @@ int rva_tracker_create(rva_ctx *ctx, int n_streams, int capacity, int max_age, d
         std::vector<double> ones(n_streams, 1.0);
         RVA_HIP(ctx, hipMemcpy(t->d_bscale, ones.data(), n_streams * 8, hipMemcpyHostToDevice));
     }
+    RVA_HIP(ctx, hipMalloc(&t->gate_cfg, n_streams * 16));
+    RVA_HIP(ctx, hipMalloc(&t->gate_state, n_streams * 16));
+    RVA_HIP(ctx, hipMalloc(&t->emitted, n_streams * 4));
+    RVA_HIP(ctx, hipMalloc(&t->processed, n_streams * 4));
+    RVA_HIP(ctx, hipMemset(t->gate_cfg, 0, n_streams * 16));
+    RVA_HIP(ctx, hipMemset(t->gate_state, 0, n_streams * 16));
+    RVA_HIP(ctx, hipMemset(t->emitted, 0, n_streams * 4));
+    RVA_HIP(ctx, hipMemset(t->processed, 0xff, n_streams * 4));
     RVA_HIP(ctx, hipHostMalloc(&t->h_slot, n_streams * 4));
     RVA_HIP(ctx, hipHostMalloc(&t->h_offs, (n_streams + 1) * 4));
     RVA_HIP(ctx, hipEventCreateWithFlags(&t->staged, hipEventDisableTiming));
-    t->h_read_bytes = sc * (8 + 32 + 8 + 4 + 4 + 4 + 4) + n_streams * 4 + 64 * 9;
+    t->h_read_bytes = sc * (8 + 32 + 8 + 4 + 4 + 4 + 4) + n_streams * 12 + 64 * 12;
     for (int i = 0; i < 2; ++i) {
         RVA_HIP(ctx, hipHostMalloc(&t->h_read[i], t->h_read_bytes, hipHostMallocMapped));
         RVA_HIP(ctx, hipHostGetDevicePointer(&t->h_read_dev[i], t->h_read[i], 0));
@@ -316,7 +362,7 @@ void rva_tracker_destroy(rva_tracker *t)
     (void)hipSetDevice(t->ctx->device);
     (void)hipDeviceSynchronize();
     void *dev[] = {t->id, t->box, t->conf, t->cls, t->age, t->hits, t->last_det, t->n_tracks, t->n_new, t->next_id, t->id_ticket, t->flags,
-                   t->d_slot, t->d_offs, t->d_gidx, t->d_bscale};
+                   t->d_slot, t->d_offs, t->d_gidx, t->d_bscale, t->gate_cfg, t->gate_state, t->emitted, t->processed};
     for (void *p : dev) (void)hipFree(p);
     void *host[] = {t->h_slot, t->h_offs, t->h_read[0], t->h_read[1]};
     for (int i = 0; i < 2; ++i) if (t->snap_done[i]) (void)hipEventDestroy(t->snap_done[i]);
@@ -325,24 +371,64 @@ void rva_tracker_destroy(rva_tracker *t)
     delete t;
 }
 
-int rva_tracker_update_f32(rva_tracker *t, const int32_t *slot_of_stream, const float *boxes, const float *scores,
-                           const int32_t *cls, const int32_t *counts, int max_det, double filter_thr,
-                           rva_stream_t stream_)
+static int update_f32_common(rva_tracker *t, const int32_t *slot_of_stream, const float *boxes, const float *scores,
+                             const int32_t *cls, const int32_t *counts, int max_det, double filter_thr, bool gated,
+                             const int32_t *motion_counts, const int32_t *motion_row, hipStream_t stream)
 {
     if (!t || !slot_of_stream) return RVA_ERR_ARG;
-    hipStream_t stream = (hipStream_t)stream_;
     bool any = false;
     K4Args a{};
     for (int s = 0; s < t->n_streams; ++s) {
-        a.kslot[s] = slot_of_stream[s];
-        any |= slot_of_stream[s] >= 0;
+        const int v = slot_of_stream[s];
+        if (v < -3 || v > 32767) return rva_fail(t->ctx, RVA_ERR_ARG, "rva_tracker_update_f32: slot_of_stream[%d] = %d out of range", s, v);
+        a.kslot[s] = (int16_t)v;
+        any |= v >= 0;
+        const int mr = gated && motion_row ? motion_row[s] : -1;
+        if (mr < -1 || mr > 32767 || (mr >= 0 && !motion_counts))
+            return rva_fail(t->ctx, RVA_ERR_ARG, "rva_tracker_update_gated_f32: motion_row[%d] = %d without counts / out of range", s, mr);
+        a.mrow[s] = (int16_t)mr;
     }
     if (any && (!boxes || !scores || !cls || !counts || max_det <= 0))
         return rva_fail(t->ctx, RVA_ERR_ARG, "rva_tracker_update_f32: detection arrays missing");
     a.boxes32 = (const float4 *)boxes; a.scores32 = scores; a.cls32 = cls; a.counts32 = counts; a.max_det = max_det;
     a.filter_thr = filter_thr;
     a.bscale = t->d_bscale;
+    a.motion_cnt = motion_counts;
+    a.gate_cfg = gated ? t->gate_cfg : nullptr;
+    a.gate_state = gated ? t->gate_state : nullptr;
     return launch_update(t, a, false, stream);
+}
+
+int rva_tracker_update_f32(rva_tracker *t, const int32_t *slot_of_stream, const float *boxes, const float *scores,
+                           const int32_t *cls, const int32_t *counts, int max_det, double filter_thr,
+                           rva_stream_t stream_)
+{
+    return update_f32_common(t, slot_of_stream, boxes, scores, cls, counts, max_det, filter_thr, false, nullptr, nullptr,
+                             (hipStream_t)stream_);
+}
+
+int rva_tracker_update_gated_f32(rva_tracker *t, const int32_t *slot_of_stream, const float *boxes, const float *scores,
+                                 const int32_t *cls, const int32_t *counts, int max_det, double filter_thr,
+                                 const int32_t *motion_counts, const int32_t *motion_row, rva_stream_t stream_)
+{
+    return update_f32_common(t, slot_of_stream, boxes, scores, cls, counts, max_det, filter_thr, true, motion_counts, motion_row,
+                             (hipStream_t)stream_);
+}
+
+int rva_tracker_set_gates(rva_tracker *t, const int32_t *adaptive_enabled, const int32_t *max_process_every,
+                          const int32_t *idle_tolerance, const int32_t *motion_min_count, int reset_state)
+{
+    if (!t || !adaptive_enabled || !max_process_every || !idle_tolerance || !motion_min_count) return RVA_ERR_ARG;
+    std::vector<int32_t> cfg((size_t)t->n_streams * 4), st((size_t)t->n_streams * 4, 0);
+    for (int s = 0; s < t->n_streams; ++s) {
+        cfg[4 * s] = adaptive_enabled[s] ? 1 : 0; cfg[4 * s + 1] = max_process_every[s]; cfg[4 * s + 2] = idle_tolerance[s];
+        cfg[4 * s + 3] = motion_min_count[s];
+        st[4 * s + 2] = 1;                                   // process_every starts at 1 (pipeline.py:106)
+    }
+    RVA_HIP(t->ctx, hipDeviceSynchronize());
+    RVA_HIP(t->ctx, hipMemcpy(t->gate_cfg, cfg.data(), cfg.size() * 4, hipMemcpyHostToDevice));
+    if (reset_state) RVA_HIP(t->ctx, hipMemcpy(t->gate_state, st.data(), st.size() * 4, hipMemcpyHostToDevice));
+    return RVA_OK;
 }
 
 int rva_tracker_update_f64(rva_tracker *t, const int32_t *active, const int32_t *offsets, const double *boxes,
@@ -351,7 +437,7 @@ int rva_tracker_update_f64(rva_tracker *t, const int32_t *active, const int32_t 
     if (!t || !active || !offsets) return RVA_ERR_ARG;
     hipStream_t stream = (hipStream_t)stream_;
     RVA_HIP(t->ctx, hipEventSynchronize(t->staged));  // previous tick's copies have left the staging buffers
-    for (int s = 0; s < t->n_streams; ++s) { t->h_slot[s] = active[s] ? 1 : 0; t->h_offs[s] = offsets[s]; }
+    for (int s = 0; s < t->n_streams; ++s) { t->h_slot[s] = active[s] == 2 ? 2 : (active[s] ? 1 : 0); t->h_offs[s] = offsets[s]; }
     t->h_offs[t->n_streams] = offsets[t->n_streams];
     RVA_HIP(t->ctx, hipMemcpyAsync(t->d_slot, t->h_slot, t->n_streams * 4, hipMemcpyHostToDevice, stream));
     RVA_HIP(t->ctx, hipMemcpyAsync(t->d_offs, t->h_offs, (t->n_streams + 1) * 4, hipMemcpyHostToDevice, stream));
@@ -403,7 +489,8 @@ int rva_tracker_assign_ids(rva_tracker *t, const int32_t *counts_all, int n_glob
 static size_t snap_off(const rva_tracker *t, int section)
 {
     const size_t sc = (size_t)t->n_streams * t->cap;
-    const size_t sizes[8] = {sc * 8, sc * 32, sc * 8, sc * 4, sc * 4, sc * 4, sc * 4, (size_t)t->n_streams * 4};
+    const size_t sizes[11] = {sc * 8, sc * 32, sc * 8, sc * 4, sc * 4, sc * 4, sc * 4, (size_t)t->n_streams * 4,
+                              (size_t)t->n_streams * 4, (size_t)t->n_streams * 4, 8};
     size_t off = 0;
     for (int i = 0; i < section; ++i) off += (sizes[i] + 63) & ~(size_t)63;
     return off;
@@ -417,13 +504,20 @@ struct SnapArgs {
     const int64_t *id; const double *box; const double *conf; const int32_t *cls, *age, *hits, *last_det, *n_tracks;
     int64_t *h_id; double *h_box; double *h_conf; int32_t *h_cls, *h_age, *h_hits, *h_last, *h_n;
     int cap;
+    const int32_t *emitted, *processed, *trk_flags, *post_flags;
+    int32_t *h_emitted, *h_processed, *h_flags;
 };
 
 __global__ void __launch_bounds__(256) k4_snapshot(SnapArgs a)
 {
     const int s = blockIdx.x;
     const int n = min(a.n_tracks[s], a.cap);
-    if (threadIdx.x == 0) a.h_n[s] = a.n_tracks[s];
+    if (threadIdx.x == 0) {
+        a.h_n[s] = a.n_tracks[s];
+        a.h_emitted[s] = a.emitted[s];
+        a.h_processed[s] = a.processed[s];
+        if (s == 0) { a.h_flags[0] = a.trk_flags[0]; a.h_flags[1] = a.post_flags[0]; }   // overflow / truncation flags ride along
+    }
     const size_t base = (size_t)s * a.cap;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         const size_t r = base + i;
@@ -446,7 +540,9 @@ int rva_tracker_snapshot_async(rva_tracker *t, int slot, rva_stream_t stream_)
     SnapArgs a{t->id, t->box, t->conf, t->cls, t->age, t->hits, t->last_det, t->n_tracks,
                (int64_t *)(h + snap_off(t, 0)), (double *)(h + snap_off(t, 1)), (double *)(h + snap_off(t, 2)),
                (int32_t *)(h + snap_off(t, 3)), (int32_t *)(h + snap_off(t, 4)), (int32_t *)(h + snap_off(t, 5)),
-               (int32_t *)(h + snap_off(t, 6)), (int32_t *)(h + snap_off(t, 7)), t->cap};
+               (int32_t *)(h + snap_off(t, 6)), (int32_t *)(h + snap_off(t, 7)), t->cap,
+               t->emitted, t->processed, t->flags, t->ctx->post_flags,
+               (int32_t *)(h + snap_off(t, 8)), (int32_t *)(h + snap_off(t, 9)), (int32_t *)(h + snap_off(t, 10))};
     k4_snapshot<<<t->n_streams, 256, 0, stream>>>(a);
     RVA_HIP(t->ctx, hipGetLastError());
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -476,6 +572,19 @@ int rva_tracker_snapshot_fetch(rva_tracker *t, int slot, int wait, int64_t *ids,
         if (age) std::memcpy(age + r, h + snap_off(t, 4) + r * 4, n * 4);
         if (hits) std::memcpy(hits + r, h + snap_off(t, 5) + r * 4, n * 4);
         if (last_det) std::memcpy(last_det + r, h + snap_off(t, 6) + r * 4, n * 4);
+    }
+    return RVA_OK;
+}
+
+int rva_tracker_snapshot_status(rva_tracker *t, int slot, int32_t *emitted, int32_t *processed, int32_t *flags)
+{
+    if (!t || slot < 0 || slot > 1) return RVA_ERR_ARG;
+    const char *h = (const char *)t->h_read[slot];
+    if (emitted) std::memcpy(emitted, h + snap_off(t, 8), (size_t)t->n_streams * 4);
+    if (processed) std::memcpy(processed, h + snap_off(t, 9), (size_t)t->n_streams * 4);
+    if (flags) {
+        const int32_t *f = (const int32_t *)(h + snap_off(t, 10));
+        *flags = (f[0] & 0xff) | ((f[1] & 0xff) << 8);
     }
     return RVA_OK;
 }

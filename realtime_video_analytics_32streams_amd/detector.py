@@ -120,8 +120,12 @@ class HipYoloDetector(BaseDetector):
             net = net.fuse().to(self.device)
             net = net.half() if self.half else net.float()
             self.net = net.to(memory_format=torch.channels_last)
-        self._post: Optional[ops.PostBuffers] = None
-        self._in: Optional[torch.Tensor] = None
+        # buffers are cached per shape and never reallocated: captured hipGraphs (pipeline.PipelinedTicks) keep raw
+        # pointers to them, and an interleaved predict() with another batch size must not free what a graph replays on
+        self._post_bufs: dict = {}
+        self._in_bufs: dict = {}
+        self._post: Optional[ops.PostBuffers] = None      # result buffers of the latest call
+        self._in: Optional[torch.Tensor] = None           # input tensor of the latest call
         if config.warmup and self.net is not None:  # detector.py:588-593
             with torch.inference_mode():
                 self._infer(torch.zeros((1, 3, *self.input_hw), device=self.device,
@@ -131,8 +135,9 @@ class HipYoloDetector(BaseDetector):
     def _preprocess(self, frames: Sequence) -> tuple[torch.Tensor, N.Letterbox]:
         n = len(frames)
         dt = torch.float16 if self.half else torch.float32
-        if self._in is None or self._in.shape[0] != n:
-            self._in = torch.empty((n, 3, *self.input_hw), dtype=dt, device=self.device)
+        self._in = self._in_bufs.get(n)
+        if self._in is None:
+            self._in = self._in_bufs[n] = torch.empty((n, 3, *self.input_hw), dtype=dt, device=self.device)
         f0 = frames[0]
         if isinstance(f0, ops.Nv12Surface):
             return ops.preprocess_nv12(frames, self.input_hw, self.half, out=self._in, ctx=self.ctx)
@@ -162,20 +167,24 @@ class HipYoloDetector(BaseDetector):
         raw = raw.contiguous()
         B = raw.shape[0]
         A = raw.shape[2] if raw.shape[1] < raw.shape[2] else raw.shape[1]
-        if self._post is None or self._post.counts.shape[0] != B or self._post.max_det != A:
-            self._post = ops.PostBuffers.allocate(B, A, raw.device)
+        self._post = self._post_bufs.get((B, A))
+        if self._post is None:
+            self._post = self._post_bufs[(B, A)] = ops.PostBuffers.allocate(B, A, raw.device)
         return ops.postprocess(raw, self.config.confidence_threshold, self.config.iou_threshold, self.config.classes,
                                metas, max_det=A, out=self._post, ctx=self.ctx)
 
     # -- API ------------------------------------------------------------------------------------
+    @staticmethod
+    def geometry_key(frame) -> tuple:
+        """Frames that may share one K1 launch: same size and kind."""
+        if isinstance(frame, ops.Nv12Surface):
+            return (int(frame.width), int(frame.height), "nv12")
+        return (int(frame.shape[1]), int(frame.shape[0]), "bgr")
+
     def predict_batch_device(self, packets: Sequence[FramePacket]) -> ops.PostBuffers:
-        """Device-resident result (no host sync): feeds the tracker kernel directly."""
-        groups = {}
-        for i, p in enumerate(packets):
-            f = p.frame
-            key = (f.width, f.height, "nv12") if isinstance(f, ops.Nv12Surface) else (f.shape[1], f.shape[0], "bgr")
-            groups.setdefault(key, []).append(i)
-        if len(groups) != 1:
+        """Device-resident result (no host sync): feeds the tracker kernel directly.  One frame geometry per call (the
+        tick pipeline groups a mixed tick by geometry and issues one call per group)."""
+        if len({self.geometry_key(p.frame) for p in packets}) != 1:
             raise ValueError("predict_batch_device needs one frame geometry per call; use predict_batch for mixed sizes")
         with torch.inference_mode():
             tensor, meta = self._preprocess([p.frame for p in packets])
@@ -186,9 +195,7 @@ class HipYoloDetector(BaseDetector):
         out: List[Optional[List[Detection]]] = [None] * len(packets)
         groups = {}
         for i, p in enumerate(packets):
-            f = p.frame
-            key = (f.width, f.height, "nv12") if isinstance(f, ops.Nv12Surface) else (f.shape[1], f.shape[0], "bgr")
-            groups.setdefault(key, []).append(i)
+            groups.setdefault(self.geometry_key(p.frame), []).append(i)
         for idxs in groups.values():
             res = self.predict_batch_device([packets[i] for i in idxs]).to_host()
             for i, r in zip(idxs, res):

@@ -353,12 +353,12 @@ class FusedYoloV8:
         return self.out
 
     def use_output(self, index: int) -> torch.Tensor:
-        """Select which of two result tensors the head kernels write (``index`` 0 / 1; the second one is allocated
-        on first use).  A pipelined caller alternates them per tick, so the post-process of tick k can still read its
-        head tensor on another HIP stream while the network of tick k+1 runs."""
+        """Select which result tensor the head kernels write (``index`` 0 is the one allocated at construction, others are
+        allocated on first use).  A pipelined caller alternates two per tick (and uses a pair per frame group), so the
+        post-process of tick k can still read its head tensor on another HIP stream while the network of tick k+1 runs."""
         if not hasattr(self, "_outs"):
-            self._outs = [self.out, None]
-        if self._outs[index] is None:
+            self._outs = {0: self.out}
+        if index not in self._outs:
             self._outs[index] = torch.empty_like(self._outs[0])
         self.out = self._outs[index]
         return self.out

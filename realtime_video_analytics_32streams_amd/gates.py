@@ -54,47 +54,123 @@ def rasterize_polygons(polygons, width: int, height: int):
     return mask
 
 
+def motion_min_count(threshold: float, n_pixels: int) -> int:
+    """Smallest changed-pixel count ``c`` with ``float(c) / float(n_pixels) >= threshold`` -- the reference's decision
+    (utils/frame_filter.py:37-39) as an integer compare, exact because the quotient is monotonic in ``c``."""
+    n = float(n_pixels)
+    c = max(0, min(n_pixels + 1, int(threshold * n)))
+    while c > 0 and float(c - 1) / n >= threshold:
+        c -= 1
+    while c <= n_pixels and not (float(c) / n >= threshold):
+        c += 1
+    return c
+
+
 class MotionGate:
-    def __init__(self, n_streams: int, width: int, height: int, thresholds: Sequence[float], ctx: Optional[N.Context] = None):
+    """``MotionFilter.should_process`` for all streams of a tick.  Like the reference (one MotionFilter per stream at that
+    stream's own frame shape, pipeline.py:156-158) every stream keeps its own geometry: it is learnt from the stream's first
+    frame, the blurred-gray history is sized for it, and a later frame of another size or kind is an error.  One K5 launch
+    per distinct geometry of the tick."""
+
+    def __init__(self, n_streams: int, width: Optional[int] = None, height: Optional[int] = None,
+                 thresholds: Sequence[float] = (), ctx: Optional[N.Context] = None):
         self.ctx = ctx or ops.context()
-        dev = torch.device("cuda", self.ctx.device)
-        self.w, self.h, self.n = width, height, n_streams
-        self.thresholds = list(thresholds)
-        self._blur = [torch.empty((2, height, width), dtype=torch.uint8, device=dev) for _ in range(n_streams)]
+        self.dev = torch.device("cuda", self.ctx.device)
+        self.n = n_streams
+        self.thresholds = list(thresholds) if len(thresholds) else [0.02] * n_streams
+        self.geom: List[Optional[tuple]] = [None] * n_streams        # (w, h, "nv12" | "bgr") per stream
+        self._blur: List[Optional[torch.Tensor]] = [None] * n_streams
         self._have_prev = [False] * n_streams
         self._flip = [0] * n_streams
-        self.counts = torch.zeros(n_streams, dtype=torch.int32, device=dev)
+        # two count rows: a pipelined caller alternates them per tick (tick k's K4 may still read its counts on another HIP
+        # stream while K5 of tick k+1 writes)
+        self.counts = torch.zeros((2, n_streams), dtype=torch.int32, device=self.dev)
+        if width is not None and height is not None:                 # geometry known up front (all streams alike)
+            for i in range(n_streams):
+                self._blur[i] = torch.empty((2, height, width), dtype=torch.uint8, device=self.dev)
+
+    @property
+    def w(self):
+        return next((g[0] for g in self.geom if g), None)
+
+    @property
+    def h(self):
+        return next((g[1] for g in self.geom if g), None)
+
+    @staticmethod
+    def _geom_of(f) -> tuple:
+        if isinstance(f, ops.Nv12Surface):
+            return (int(f.width), int(f.height), "nv12")
+        if not (isinstance(f, torch.Tensor) and f.is_cuda and f.dtype == torch.uint8 and f.dim() == 3 and f.shape[2] == 3):
+            raise ValueError("motion gate frames must be Nv12Surface or device uint8 BGR [h, w, 3] tensors")
+        return (int(f.shape[1]), int(f.shape[0]), "bgr")
+
+    def min_count(self, i: int) -> int:
+        """Device-gate form of stream i's threshold (needs the stream's geometry, i.e. its first frame)."""
+        g = self.geom[i]
+        return motion_min_count(self.thresholds[i], g[0] * g[1]) if g else 0
+
+    def launch(self, surfaces: Sequence, slot: int = 0) -> List[int]:
+        """Enqueue K5 for the streams that delivered a frame (no host sync).  Returns, per stream, the row of
+        ``self.counts[slot]`` that will hold its changed-pixel count (-1 on the first frame of a stream), or -1 for no frame."""
+        if len(surfaces) != self.n:
+            raise ValueError(f"MotionGate was built for {self.n} streams, got {len(surfaces)} frames")
+        rows = [-1] * self.n
+        groups = {}
+        for i, f in enumerate(surfaces):
+            if f is None:
+                continue
+            g = self._geom_of(f)
+            if self.geom[i] is None:
+                if self._blur[i] is not None and tuple(self._blur[i].shape[1:]) != (g[1], g[0]):
+                    raise ValueError(f"motion gate stream {i}: frame is {g[0]}x{g[1]}, the gate was built for "
+                                     f"{self._blur[i].shape[2]}x{self._blur[i].shape[1]}")
+                self.geom[i] = g
+                if self._blur[i] is None:
+                    self._blur[i] = torch.empty((2, g[1], g[0]), dtype=torch.uint8, device=self.dev)
+            elif self.geom[i] != g:
+                raise ValueError(f"motion gate stream {i}: frame geometry changed from {self.geom[i]} to {g} "
+                                 "(the history buffer of a stream has one size, like the reference's MotionFilter)")
+            groups.setdefault(g, []).append(i)
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        row0 = 0
+        for (w, h, kind), idx in groups.items():
+            for b0 in range(0, len(idx), N.RVA_MAX_BATCH):
+                part = idx[b0:b0 + N.RVA_MAX_BATCH]
+                prev, _d = N.ptr_array([self._blur[i][self._flip[i] ^ 1].data_ptr() if self._have_prev[i] else 0 for i in part])
+                cur, _e = N.ptr_array([self._blur[i][self._flip[i]].data_ptr() for i in part])
+                cnt = C.c_void_p(self.counts[slot].data_ptr() + 4 * row0)
+                if kind == "nv12":
+                    yp, _a = N.ptr_array([surfaces[i].y.data_ptr() for i in part])
+                    up, _b = N.ptr_array([surfaces[i].uv.data_ptr() for i in part])
+                    pp, _c = N.i32_array([surfaces[i].pitch for i in part])
+                    mp, _m = N.ptr_array([surfaces[i].mask.data_ptr() if surfaces[i].mask is not None else 0 for i in part])
+                    rc = N.lib().rva_motion_nv12_masked_batch(self.ctx.handle, yp, up, pp, mp, prev, cur, len(part), w, h, cnt, stream)
+                else:
+                    fp, _a = N.ptr_array([surfaces[i].data_ptr() for i in part])
+                    rb, _b = N.i32_array([int(surfaces[i].stride(0)) for i in part])
+                    rc = N.lib().rva_motion_bgr_batch(self.ctx.handle, fp, rb, prev, cur, len(part), w, h, cnt, stream)
+                self.ctx.check(rc, "rva_motion_*_batch")
+                for k, i in enumerate(part):
+                    rows[i] = row0 + k
+                    self._have_prev[i] = True
+                    self._flip[i] ^= 1
+                row0 += len(part)
+        return rows
 
     def step(self, surfaces: Sequence) -> List[bool]:
         """``surfaces[i]`` is stream i's frame_for_detection of this tick: an ``Nv12Surface`` (its ``mask`` is
         honoured), a uint8 BGR device tensor [h, w, 3] (downsampled frame), or None (no frame).  Returns
         should_process per stream (True for a stream's first frame, frame_filter.py:33-35).  One host sync."""
-        idx = [i for i, s in enumerate(surfaces) if s is not None]
+        rows = self.launch(surfaces)
         out = [True] * len(surfaces)
-        if not idx:
+        if all(r < 0 for r in rows):
             return out
-        prev, _d = N.ptr_array([self._blur[i][self._flip[i] ^ 1].data_ptr() if self._have_prev[i] else 0 for i in idx])
-        cur, _e = N.ptr_array([self._blur[i][self._flip[i]].data_ptr() for i in idx])
-        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        if isinstance(surfaces[idx[0]], ops.Nv12Surface):
-            yp, _a = N.ptr_array([surfaces[i].y.data_ptr() for i in idx])
-            up, _b = N.ptr_array([surfaces[i].uv.data_ptr() for i in idx])
-            pp, _c = N.i32_array([surfaces[i].pitch for i in idx])
-            mp, _m = N.ptr_array([surfaces[i].mask.data_ptr() if surfaces[i].mask is not None else 0 for i in idx])
-            rc = N.lib().rva_motion_nv12_masked_batch(self.ctx.handle, yp, up, pp, mp, prev, cur, len(idx), self.w, self.h,
-                                                      C.c_void_p(self.counts.data_ptr()), stream)
-        else:
-            fp, _a = N.ptr_array([surfaces[i].data_ptr() for i in idx])
-            rb, _b = N.i32_array([int(surfaces[i].stride(0)) for i in idx])
-            rc = N.lib().rva_motion_bgr_batch(self.ctx.handle, fp, rb, prev, cur, len(idx), self.w, self.h,
-                                              C.c_void_p(self.counts.data_ptr()), stream)
-        self.ctx.check(rc, "rva_motion_*_batch")
-        cnt = self.counts[:len(idx)].cpu().tolist()
-        for k, i in enumerate(idx):
-            if self._have_prev[i]:
-                out[i] = (float(cnt[k]) / float(self.w * self.h)) >= self.thresholds[i]
-            self._have_prev[i] = True
-            self._flip[i] ^= 1
+        cnt = self.counts[0].cpu().tolist()
+        for i, r in enumerate(rows):
+            if r >= 0 and cnt[r] >= 0:                                  # -1: first frame of the stream
+                g = self.geom[i]
+                out[i] = (float(cnt[r]) / float(g[0] * g[1])) >= self.thresholds[i]
         return out
 
 

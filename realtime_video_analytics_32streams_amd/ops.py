@@ -291,21 +291,64 @@ class DeviceTracker:
         except Exception:  # noqa: BLE001
             pass
 
-    def update_from_post(self, slot_of_stream: Sequence[int], post: Optional[PostBuffers], filter_thr: float):
+    def update_from_post(self, slot_of_stream: Sequence[int], post: Optional[PostBuffers], filter_thr: float,
+                         gated: bool = False, motion: Optional[Tuple[torch.Tensor, Sequence[int]]] = None):
+        """K4 over the streams of one launch.  ``slot_of_stream[s]``: batch row of ``post``, -1 no frame, -2 skipped frame,
+        -3 owned by another launch of this tick.  ``gated``: decide the motion / adaptive-fps gates on the device
+        (``set_gates``); ``motion = (counts int32 device tensor, row per stream or -1)`` feeds the motion gate."""
+        if len(slot_of_stream) != self.n_streams:
+            raise ValueError(f"slot_of_stream needs {self.n_streams} entries (one per tracker stream)")
         sp, _k = N.i32_array(list(slot_of_stream))
         nul = C.c_void_p(None)
-        if post is None:
-            rc = N.lib().rva_tracker_update_f32(self.handle, sp, nul, nul, nul, nul, 0, float(filter_thr), _stream_ptr())
+        arrs = (nul, nul, nul, nul, 0) if post is None else \
+            (C.c_void_p(post.boxes.data_ptr()), C.c_void_p(post.scores.data_ptr()), C.c_void_p(post.cls.data_ptr()),
+             C.c_void_p(post.counts.data_ptr()), post.max_det)
+        if gated:
+            if motion is not None:
+                cnt, rows = motion
+                assert cnt.is_cuda and cnt.dtype == torch.int32 and len(rows) == self.n_streams
+                mp, _m = N.i32_array(list(rows))
+                cp = C.c_void_p(cnt.data_ptr())
+            else:
+                mp, cp = None, nul
+            rc = N.lib().rva_tracker_update_gated_f32(self.handle, sp, *arrs, float(filter_thr), cp, mp, _stream_ptr())
         else:
-            rc = N.lib().rva_tracker_update_f32(self.handle, sp, C.c_void_p(post.boxes.data_ptr()),
-                                                C.c_void_p(post.scores.data_ptr()), C.c_void_p(post.cls.data_ptr()),
-                                                C.c_void_p(post.counts.data_ptr()), post.max_det, float(filter_thr),
-                                                _stream_ptr())
+            rc = N.lib().rva_tracker_update_f32(self.handle, sp, *arrs, float(filter_thr), _stream_ptr())
         self.ctx.check(rc, "rva_tracker_update_f32")
 
-    def update_from_host(self, per_stream: dict):
-        """``per_stream[s] = (boxes f64 [D,4], conf f64 [D], cls i64 [D])`` for the streams to update."""
-        active = [0] * self.n_streams
+    def set_gates(self, adaptive_enabled: Sequence[int], max_process_every: Sequence[int], idle_tolerance: Sequence[int],
+                  motion_min_count: Sequence[int], reset: bool = True) -> None:
+        """Per-stream parameters of the device-side gates (host-synchronous; see rva_tracker_set_gates)."""
+        arrs = []
+        for v in (adaptive_enabled, max_process_every, idle_tolerance, motion_min_count):
+            if len(v) != self.n_streams:
+                raise ValueError(f"gate arrays need {self.n_streams} entries")
+            arrs.append(N.i32_array([int(x) for x in v]))
+        self.ctx.check(N.lib().rva_tracker_set_gates(self.handle, arrs[0][0], arrs[1][0], arrs[2][0], arrs[3][0], 1 if reset else 0),
+                       "rva_tracker_set_gates")
+
+    def snapshot_status(self, slot: int) -> Tuple[np.ndarray, np.ndarray, int]:
+        """(emitted[S], processed[S], flags) that rode along in snapshot ``slot`` (valid once the slot's copy is done)."""
+        em = np.empty(self.n_streams, np.int32); pr = np.empty(self.n_streams, np.int32)
+        fl = C.c_int32()
+        self.ctx.check(N.lib().rva_tracker_snapshot_status(self.handle, slot, C.c_void_p(em.ctypes.data), C.c_void_p(pr.ctypes.data),
+                                                           C.byref(fl)), "rva_tracker_snapshot_status")
+        return em, pr, int(fl.value)
+
+    @staticmethod
+    def raise_on_flags(flags: int) -> None:
+        """The reference's NMS and tracker are unbounded; the device tables are not.  Any truncation is an error."""
+        if flags & 0x1:
+            raise RuntimeError("tracker table capacity exceeded (detections were dropped); construct IouTracker with a larger `capacity`")
+        if flags & 0x100:
+            raise RuntimeError("post-process kept more boxes than max_det for an image (survivors were dropped)")
+        if flags & 0x200:
+            raise RuntimeError("post-process: more thresholded anchors than the NMS sort holds (candidates were dropped)")
+
+    def update_from_host(self, per_stream: dict, others_untouched: bool = False):
+        """``per_stream[s] = (boxes f64 [D,4], conf f64 [D], cls i64 [D])`` for the streams to update.  The other streams
+        count as "no update this tick" unless ``others_untouched`` (another launch of the same tick owns them)."""
+        active = [2 if others_untouched else 0] * self.n_streams
         offs = [0] * (self.n_streams + 1)
         bl, cl, kl = [], [], []
         tot = 0
@@ -354,6 +397,8 @@ class DeviceTracker:
             rc = N.lib().rva_tracker_assign_ids(self.handle, C.c_void_p(None), 0, None, _stream_ptr())
         else:
             assert counts_all.is_cuda and counts_all.dtype == torch.int32 and counts_all.is_contiguous()
+            if global_index is not None and len(global_index) != self.n_streams:   # the C side reads n_streams entries
+                raise ValueError(f"global_index needs {self.n_streams} entries (pad unused tracker streams with 0)")
             gp, _k = N.i32_array(list(global_index)) if global_index is not None else (None, None)
             rc = N.lib().rva_tracker_assign_ids(self.handle, C.c_void_p(counts_all.data_ptr()), int(counts_all.numel()),
                                                 gp, _stream_ptr())

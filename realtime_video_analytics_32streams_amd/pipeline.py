@@ -1,33 +1,44 @@
 """Tick-batched orchestrator for the hot path.
 
 The reference runs ``_process_packet`` once per frame per stream on one asyncio thread
-(pipeline.py:143-212): detector.predict -> filter_detections -> tracker.update.  Here one *tick*
-takes at most one frame from every stream of this GPU and runs the same order of operations for
-all of them at once, without a host round trip between the stages:
+(pipeline.py:143-212): [roi -> downsample -> motion gate -> adaptive-fps gate] -> detector.predict ->
+_rescale_detections -> filter_detections -> tracker.update.  Here one *tick* takes at most one frame from every
+stream of this GPU and runs the same order of operations for all of them at once, without a host round trip
+between the stages:
 
-    K1 pre-process (1 launch) -> detector network (PyTorch-ROCm) -> K2 decode + K3 NMS
-    -> K4 tracker update (filter_detections fused in) -> id assignment -> one read-back.
+    K5 motion counts -> per frame group: K1 pre-process (1 launch) -> detector network -> K2 decode + K3 NMS
+    -> K4 tracker update (gates, _rescale_detections and filter_detections fused in) -> id assignment -> one read-back.
 
-Canonical order (SURVEY.md hard part 2): tick-major, streams in config order.  Skipped frames
-(``process=False``: the motion / adaptive-fps gates of pipeline.py:156-170) age the stream's tracks
-exactly like ``tracker.update(name, [])`` (pipeline.py:214-222).  A stream that delivers no frame in
-a tick is masked out and does not stall the others.
+A *frame group* is the set of streams of a tick that share a detector object and a frame geometry: every stream is
+routed to the detector its ``detector_id`` names (one detector object per id, shared by its streams, as in
+pipeline.py:470-489) and a tick with several resolutions issues one K1 / network / K2-K3 / K4 sequence per group.
+All groups update the ONE shared tracker; ids are handed out after the last group, so they do not depend on the
+grouping.  Detectors without a batched device path (the temporal heads, which return host detections) are called
+per packet like the reference does and feed the tracker through its float64 entry point.
 
-Multi-GPU: each rank owns a contiguous slice of the streams; the only exchange is the per-tick
-all-gather of ``n_streams`` int32 new-track counts (RCCL) feeding ``assign_ids`` -- see
-:mod:`.dist`.
+Canonical order (SURVEY.md hard part 2): tick-major, streams in config order.  Skipped frames (the motion /
+adaptive-fps gates of pipeline.py:156-170) age the stream's tracks exactly like ``tracker.update(name, [])``
+(pipeline.py:214-222).  A stream that delivers no frame in a tick is masked out and does not stall the others.
+
+Gates: ``TickPipeline.tick`` decides them on the host (one small read-back of the K5 counts; gated-out frames never
+reach the detector), ``PipelinedTicks`` decides them on the device inside K4 (no host sync; the detector has then run
+on every delivered frame).  Both give the same tables.
+
+Multi-GPU: each rank owns a contiguous slice of the streams; the only exchange is the per-tick all-gather of
+``n_streams`` int32 new-track counts (RCCL) feeding ``assign_ids`` -- see :mod:`.dist`.
 """
 from __future__ import annotations
 
 import time
-from dataclasses import dataclass, field
-from typing import Dict, List, Optional, Sequence
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
 
+import numpy as np
 import torch
 
 from . import ops
 from .config import PipelineConfig, StreamConfig
-from .detector import HipYoloDetector, create_detector
+from .detector import Detection, create_detector, filter_detections
 from .gates import AdaptiveFps, MotionGate, rasterize_polygons
 from .tracker import IouTracker, Track
 from .video_stream import FramePacket, open_stream
@@ -56,47 +67,101 @@ class StreamCounters:
         self.active_tracks[stream] = tracks
 
 
-class TickPipeline:
-    """All streams of one GPU, one detector, one tracker."""
+@dataclass
+class _Group:
+    """Streams of one tick that share a detector object and a frame geometry (one K1 launch, one network batch)."""
+    det: int                 # index into TickPipeline.detectors
+    key: tuple               # (w, h, kind) of the frames
+    idx: List[int]           # stream indices, ascending (batch row r holds stream idx[r])
 
-    def __init__(self, streams: Sequence[StreamConfig], detector: HipYoloDetector, tracker: IouTracker,
+
+@dataclass
+class _TickPlan:
+    groups: List[_Group]
+    host_idx: List[int]      # live streams whose detector has no batched device path (predict(packet) per stream)
+    base: List[int]          # per tracker slot: -1 no frame / -2 skipped by the caller / -3 handled by a group or host path
+    signature: tuple         # what a captured hipGraph of this tick shape depends on
+
+
+class TickPipeline:
+    """All streams of one GPU, their detectors, one tracker."""
+
+    def __init__(self, streams: Sequence[StreamConfig], detector, tracker: IouTracker,
                  sources: Optional[Sequence] = None, id_sync=None, first_global_index: int = 0,
                  n_global_streams: Optional[int] = None):
+        """``detector``: one detector object for every stream, or a sequence with one entry per stream (entries may repeat:
+        streams that name the same ``detector_id`` share one object, pipeline.py:470-489)."""
         self.streams = list(streams)
-        self.detector, self.tracker = detector, tracker
+        per_stream = list(detector) if isinstance(detector, (list, tuple)) else [detector] * len(self.streams)
+        if len(per_stream) != len(self.streams):
+            raise ValueError("one detector per stream is required")
+        self.detectors: List = []
+        self.det_of: List[int] = []
+        for d in per_stream:
+            k = next((j for j, e in enumerate(self.detectors) if e is d), None)
+            if k is None:
+                self.detectors.append(d)
+                k = len(self.detectors) - 1
+            self.det_of.append(k)
+        self.detector = self.detectors[0]          # the common single-detector case keeps its old attribute
+        self.tracker = tracker
+        self.ctx = getattr(self.detector, "ctx", None) or ops.context()
         self.sources = list(sources) if sources is not None else [open_stream(s, i) for i, s in enumerate(self.streams)]
         self.names = [s.name for s in self.streams]
         self.slots = tracker.register_streams(self.names)
         assert self.slots == sorted(self.slots), "streams must be registered in canonical (config) order"
         self.counters = StreamCounters()
         self.id_sync = id_sync
-        self.global_index = [first_global_index + i for i in range(len(self.streams))]
+        dev = tracker.device_tracker
+        # rva_tracker_assign_ids reads one entry per TRACKER stream: pad the streams this pipeline does not use
+        self.global_index = [0] * dev.n_streams
+        for i, sl in enumerate(self.slots):
+            self.global_index[sl] = first_global_index + i
         self.n_global = n_global_streams or len(self.streams)
         self._tick = 0
         # pre-detector gates (SURVEY 8f-2), configured by the reference's StreamConfig keys
         self.adaptive = [AdaptiveFps(s) for s in self.streams]
         self._motion: Optional[MotionGate] = None
         self._motion_on = [bool(s.motion_filter) for s in self.streams]
+        self.has_gates = any(self._motion_on) or any(a.enabled for a in self.adaptive)
+        self._gates_uploaded: Optional[tuple] = None
         self._roi_masks: Dict[int, torch.Tensor] = {}          # stream index -> device mask (built at the first frame)
-        ratios = {float(s.downsample_ratio) for s in self.streams}
-        if len(ratios) > 1 and any(r < 0.999 for r in ratios):
-            raise NotImplementedError("TickPipeline batches one geometry per tick: use the same downsample_ratio on all streams")
-        self.downsample_ratio = ratios.pop() if ratios else 1.0
-        if self.downsample_ratio < 0.999:                       # _rescale_detections, pipeline.py:224-240
-            scale = 1.0 / max(self.downsample_ratio, 1e-6)
-            tracker.device_tracker.set_box_scale([scale] * tracker.device_tracker.n_streams)
+        self.ratios = [float(s.downsample_ratio) for s in self.streams]
+        if any(r < 0.999 for r in self.ratios):                 # _rescale_detections, pipeline.py:224-240
+            scales = [1.0] * dev.n_streams
+            for i, r in enumerate(self.ratios):
+                if r < 0.999:
+                    scales[self.slots[i]] = 1.0 / max(r, 1e-6)
+            dev.set_box_scale(scales)
 
+    @classmethod
+    def from_config(cls, cfg: PipelineConfig, **kw) -> "TickPipeline":
+        """One detector object per detector id (``__default__`` + ``detectors``), each stream routed by its
+        ``detector_id`` (pipeline.py:470-489); only the ids some enabled stream uses are built."""
+        streams = [s for s in cfg.streams if s.enabled]
+        if not streams:
+            raise RuntimeError("No stream workers started")       # pipeline.py:512-513
+        built: Dict[str, object] = {}
+        per_stream = []
+        for s in streams:
+            key = s.detector_id or "__default__"
+            if key not in built:
+                built[key] = create_detector(cfg.detector_for(s))
+            per_stream.append(built[key])
+        trk = IouTracker(cfg.tracker, max_streams=max(len(streams), 1))
+        return cls(streams, per_stream, trk, **kw)
+
+    # -- what reaches the detector ----------------------------------------------------------------------------
     def _frames_for_detection(self, packets: Sequence[Optional[FramePacket]]) -> List[Optional[FramePacket]]:
         """apply_roi -> downsample (pipeline.py:148-154): returns packets whose ``frame`` is what the reference
         calls ``frame_for_detection`` (masked surface, or the downsampled BGR image)."""
         need_roi = any(s.roi_polygons for s in self.streams)
-        if not need_roi and self.downsample_ratio >= 0.999:
+        if not need_roi and all(r >= 0.999 for r in self.ratios):
             return list(packets)
-        out: List[Optional[FramePacket]] = []
-        live = []
+        out: List[Optional[FramePacket]] = list(packets)
+        by_size: Dict[tuple, List[int]] = {}
         for i, p in enumerate(packets):
             if p is None or not isinstance(p.frame, ops.Nv12Surface):
-                out.append(p)
                 continue
             f = p.frame
             if self.streams[i].roi_polygons:
@@ -104,31 +169,32 @@ class TickPipeline:
                     m = rasterize_polygons(self.streams[i].roi_polygons, f.width, f.height)
                     self._roi_masks[i] = torch.from_numpy(m).to(f.y.device)
                 f = ops.Nv12Surface(f.y, f.uv, f.width, f.height, mask=self._roi_masks[i])
-            out.append(FramePacket(stream=p.stream, frame=f, frame_id=p.frame_id, timestamp=p.timestamp))
-            live.append(i)
-        if self.downsample_ratio < 0.999 and live:
-            f0 = out[live[0]].frame
-            dw, dh = int(f0.width * self.downsample_ratio), int(f0.height * self.downsample_ratio)
-            small = ops.resize_nv12_to_bgr([out[i].frame for i in live], (dw, dh), ctx=self.detector.ctx)
-            for k, i in enumerate(live):
+                out[i] = FramePacket(stream=p.stream, frame=f, frame_id=p.frame_id, timestamp=p.timestamp)
+            if self.ratios[i] < 0.999:
+                dw, dh = int(f.width * self.ratios[i]), int(f.height * self.ratios[i])
+                by_size.setdefault((f.width, f.height, dw, dh), []).append(i)
+        for (_, _, dw, dh), idx in by_size.items():               # one resize launch per (source, target) geometry
+            small = ops.resize_nv12_to_bgr([out[i].frame for i in idx], (dw, dh), ctx=self.ctx)
+            for k, i in enumerate(idx):
                 p = out[i]
                 out[i] = FramePacket(stream=p.stream, frame=small[k], frame_id=p.frame_id, timestamp=p.timestamp)
         return out
 
+    def _motion_gate(self) -> MotionGate:
+        if self._motion is None:
+            self._motion = MotionGate(len(self.streams), thresholds=[s.motion_threshold for s in self.streams], ctx=self.ctx)
+        return self._motion
+
     def _gate(self, packets: Sequence[Optional[FramePacket]]) -> List[bool]:
-        """should-process decision per stream, in the reference's order: motion gate (pipeline.py:156-163), then
-        adaptive-fps gate (:165-170).  ``AdaptiveFps.should_process`` runs for every packet (the frame index of
-        pipeline.py:144 advances even when the motion gate already dropped the frame)."""
+        """Host form of the gates: should-process per stream, in the reference's order: motion gate (pipeline.py:156-163),
+        then adaptive-fps gate (:165-170).  ``AdaptiveFps.should_process`` runs for every packet (the frame index of
+        pipeline.py:144 advances even when the motion gate already dropped the frame).  One small host sync."""
         n = len(packets)
         motion_ok = [True] * n
         if any(self._motion_on):
             surf = [p.frame if (p is not None and self._motion_on[i]) else None for i, p in enumerate(packets)]
-            first = next((f for f in surf if f is not None), None)
-            if first is not None:
-                if self._motion is None:
-                    fw, fh = (first.width, first.height) if isinstance(first, ops.Nv12Surface) else (int(first.shape[1]), int(first.shape[0]))
-                    self._motion = MotionGate(n, fw, fh, [s.motion_threshold for s in self.streams], ctx=self.detector.ctx)
-                motion_ok = self._motion.step(surf)
+            if any(f is not None for f in surf):
+                motion_ok = self._motion_gate().step(surf)
         out = []
         for i, p in enumerate(packets):
             if p is None:
@@ -138,150 +204,260 @@ class TickPipeline:
             out.append(motion_ok[i] and adaptive_ok)
         return out
 
-    @classmethod
-    def from_config(cls, cfg: PipelineConfig, **kw) -> "TickPipeline":
-        streams = [s for s in cfg.streams if s.enabled]
-        det = create_detector(cfg.detector_for(streams[0]))
-        trk = IouTracker(cfg.tracker, max_streams=max(len(streams), 1))
-        return cls(streams, det, trk, **kw)
-
-    # the device part of a tick: no host synchronisation inside --------------------------------------
-    def enqueue(self, packets: Sequence[Optional[FramePacket]], process: Optional[Sequence[bool]] = None):
-        live = [(i, p) for i, p in enumerate(packets) if p is not None and (process is None or process[i])]
-        n_s = self.tracker.device_tracker.n_streams
-        slot_of_stream = [-1] * n_s
-        post = None
-        if live:
-            post = self.detector.predict_batch_device([p for _, p in live])
-            for row, (i, _) in enumerate(live):
-                slot_of_stream[self.slots[i]] = row
-        for i, p in enumerate(packets):
-            if p is not None and process is not None and not process[i]:
-                slot_of_stream[self.slots[i]] = -2       # skipped frame: ages the tracks
+    def _device_gates(self, packets: Sequence[Optional[FramePacket]], slot: int = 0) -> Optional[Tuple[torch.Tensor, List[int]]]:
+        """Device form: enqueue K5 (no sync; counts go to row ``slot`` of the gate's two count buffers) and make sure the
+        tracker holds the gate parameters.  Returns the ``motion`` argument of ``DeviceTracker.update_from_post`` (None
+        when no stream has a motion gate)."""
         dev = self.tracker.device_tracker
-        dev.update_from_post(slot_of_stream, post, self.detector.config.confidence_threshold)
+        motion = None
+        mg = None
+        if any(self._motion_on):
+            surf = [p.frame if (p is not None and self._motion_on[i]) else None for i, p in enumerate(packets)]
+            mg = self._motion_gate()
+            rows = mg.launch(surf, slot)
+            full = [-1] * dev.n_streams
+            for i, r in enumerate(rows):
+                full[self.slots[i]] = r
+            motion = (mg.counts[slot], full)
+        key = tuple(mg.min_count(i) if (mg and self._motion_on[i]) else 0 for i in range(len(self.streams)))
+        if self._gates_uploaded != key:           # first tick, or a motion-gated stream just showed its geometry
+            en, mx, tol, mc = ([0] * dev.n_streams for _ in range(4))
+            for i, a in enumerate(self.adaptive):
+                sl = self.slots[i]
+                en[sl], mx[sl], tol[sl], mc[sl] = int(a.enabled), a.max_process_every, a.idle_tolerance, key[i]
+            dev.set_gates(en, mx, tol, mc, reset=self._gates_uploaded is None)
+            self._gates_uploaded = key
+        return motion
+
+    # -- the shape of a tick ----------------------------------------------------------------------------------
+    def plan_tick(self, packets: Sequence[Optional[FramePacket]], process: Optional[Sequence[bool]] = None) -> _TickPlan:
+        n_s = self.tracker.device_tracker.n_streams
+        base = [-1] * n_s
+        groups: Dict[tuple, _Group] = {}
+        host_idx: List[int] = []
+        for i, p in enumerate(packets):
+            if p is None:
+                continue
+            if process is not None and not process[i]:
+                base[self.slots[i]] = -2                           # skipped frame: ages the tracks
+                continue
+            base[self.slots[i]] = -3
+            d = self.detectors[self.det_of[i]]
+            if hasattr(d, "predict_batch_device"):
+                key = (self.det_of[i],) + d.geometry_key(p.frame)
+                g = groups.get(key)
+                if g is None:
+                    g = groups[key] = _Group(self.det_of[i], key[1:], [])
+                g.idx.append(i)
+            else:
+                host_idx.append(i)
+        gl = list(groups.values())
+        sig = (tuple((g.det, g.key, tuple(g.idx)) for g in gl), tuple(host_idx), tuple(base))
+        return _TickPlan(gl, host_idx, base, sig)
+
+    def _kslot(self, plan: _TickPlan, g: Optional[_Group], first: bool) -> List[int]:
+        """slot_of_stream of one K4 launch: the group's streams map to their batch rows, the FIRST launch of a tick also
+        carries the no-frame (-1) and skipped (-2) streams, everything else belongs to another launch (-3)."""
+        ks = list(plan.base) if first else [-3] * len(plan.base)
+        if g is not None:
+            for row, i in enumerate(g.idx):
+                ks[self.slots[i]] = row
+        return ks
+
+    def _host_path(self, plan: _TickPlan, packets) -> None:
+        """Detectors that return host detections (temporal heads): predict(packet) -> _rescale_detections ->
+        filter_detections per stream, as the reference does (pipeline.py:179-182), then one float64 tracker launch."""
+        if not plan.host_idx:
+            return
+        per = {}
+        self._host_dets = getattr(self, "_host_dets", {})
+        for i in plan.host_idx:
+            det = self.detectors[self.det_of[i]]
+            dets = det.predict(packets[i])
+            if self.ratios[i] < 0.999:
+                sc = 1.0 / max(self.ratios[i], 1e-6)
+                for d in dets:
+                    x1, y1, x2, y2 = d.bbox_xyxy
+                    d.bbox_xyxy = (x1 * sc, y1 * sc, x2 * sc, y2 * sc)
+            kept = filter_detections(dets, det.config.confidence_threshold)
+            self._host_dets[i] = kept
+            per[self.slots[i]] = IouTracker._arrays(kept)
+        self.tracker.device_tracker.update_from_host(per, others_untouched=True)
+
+    # the device part of a tick: no host synchronisation inside (batched detectors) ---------------------------
+    def enqueue(self, packets: Sequence[Optional[FramePacket]], process: Optional[Sequence[bool]] = None,
+                device_gates: bool = False):
+        plan = self.plan_tick(packets, process)
+        dev = self.tracker.device_tracker
+        gated = device_gates and self.has_gates
+        motion = self._device_gates(packets) if gated else None
+        posts = []
+        first = True
+        for g in plan.groups:
+            det = self.detectors[g.det]
+            post = det.predict_batch_device([packets[i] for i in g.idx])
+            dev.update_from_post(self._kslot(plan, g, first), post, det.config.confidence_threshold, gated=gated, motion=motion)
+            posts.append(post)
+            first = False
+        if first:                                                  # no batched group: the -1 / -2 streams still need their launch
+            dev.update_from_post(self._kslot(plan, None, True), None, 0.0, gated=gated, motion=motion)
+        self._host_path(plan, packets)
+        self.assign_ids()
+        return plan, posts
+
+    def assign_ids(self) -> None:
+        dev = self.tracker.device_tracker
         if self.id_sync is None:
             dev.assign_ids()
         else:
-            counts_all = self.id_sync.all_gather_counts(dev.new_counts_tensor()[:len(self.streams)])
-            dev.assign_ids(counts_all, self.global_index + [0] * (n_s - len(self.streams)))
-        return post
+            n = len(self.streams)
+            dev.assign_ids(self.id_sync.all_gather_counts(dev.new_counts_tensor()[:n]), self.global_index)
 
-    def tick(self, process: Optional[Sequence[bool]] = None) -> TickResult:
-        t0 = time.perf_counter()
-        packets = self._frames_for_detection([src.next_packet() for src in self.sources])
-        if process is None and (any(self._motion_on) or any(a.enabled for a in self.adaptive)):
-            process = self._gate(packets)
-        post = self.enqueue(packets, process)
-        tables = self.tracker.device_tracker.read_all()          # the one host sync of the tick
-        names = [n for n, p in zip(self.names, packets) if p is not None]
-        tabs = [tables[self.slots[i]] for i, p in enumerate(packets) if p is not None]
-        tracks = dict(zip(names, self.tracker.tracks_from_tables(names, tabs)))
-        emitted = {}
-        if post is not None:
-            # len(filtered): detections that survive filter_detections (float64 compare on widened scores)
-            counts = post.counts.cpu().numpy()
-            thr = self.detector.config.confidence_threshold
-            scores = post.scores[:, :max(int(counts.max()), 1)].double().cpu().numpy()
-            row = 0
-            for i, p in enumerate(packets):
-                if p is None or (process is not None and not process[i]):
-                    continue
-                emitted[self.names[i]] = int((scores[row, :counts[row]] >= thr).sum())
-                row += 1
+    def finish(self, packets: Sequence[Optional[FramePacket]], tables: Sequence[dict], status, t0: float) -> TickResult:
+        """Host bookkeeping once a tick's snapshot is on the host: Track objects, counters, overflow flags, and (host-gated
+        mode) the adaptive-fps state."""
+        emitted_all, processed_all, flags = status
+        ops.DeviceTracker.raise_on_flags(flags)
+        live = [i for i, p in enumerate(packets) if p is not None]
+        names = [self.names[i] for i in live]
+        tabs = [tables[self.slots[i]] for i in live]
+        host_dets = getattr(self, "_host_dets", {})
+        tracks = {}
+        for i, n, t in zip(live, names, tabs):
+            tracks[n] = self.tracker._materialise(n, t, host_dets.get(i, ()))
+        host_dets.clear()
+        emitted = {self.names[i]: int(emitted_all[self.slots[i]]) for i in live if processed_all[self.slots[i]] == 1}
         for n in names:
             self.counters.update(n, 1, emitted.get(n, 0), len(tracks[n]))
-        for i, p in enumerate(packets):                     # pipeline.py:197 / :222 _adjust_adaptive_state
-            if p is not None:
-                self.adaptive[i].update(emitted.get(self.names[i], 0), len(tracks[self.names[i]]))
         self._tick += 1
         return TickResult(self._tick - 1, tracks, emitted, time.perf_counter() - t0)
+
+    def tick(self, process: Optional[Sequence[bool]] = None, device_gates: bool = False) -> TickResult:
+        """One synchronous tick.  Gates: decided on the host by default (gated-out frames never reach the detector);
+        ``device_gates=True`` decides them inside K4 like :class:`PipelinedTicks` does (every delivered frame runs through
+        the detector; same decisions, and bit-identical detector batches with the pipelined mode).  Use one of the two
+        modes for the life of a pipeline: each keeps its own adaptive-fps state."""
+        t0 = time.perf_counter()
+        packets = self._frames_for_detection([src.next_packet() for src in self.sources])
+        if process is None and self.has_gates and not device_gates:
+            process = self._gate(packets)
+        self.enqueue(packets, process, device_gates=device_gates)
+        dev = self.tracker.device_tracker
+        tables = dev.read_all()                                    # the one host sync of the tick (snapshot slot 0)
+        res = self.finish(packets, tables, dev.snapshot_status(0), t0)
+        if not device_gates:
+            for i, p in enumerate(packets):                        # pipeline.py:197 / :222 _adjust_adaptive_state
+                if p is not None:
+                    self.adaptive[i].update(res.detections_emitted.get(self.names[i], 0), len(res.tracks[self.names[i]]))
+        return res
 
 
 class PipelinedTicks:
     """Throughput mode of :class:`TickPipeline`: ``depth`` ticks in flight, no host round trip inside a tick.
 
-    Two HIP streams with fixed roles.  Stream A: K1 (eager) + the detector network; stream B: K2/K3 -> K4 -> global ids
-    -> D2H snapshot of the track tables (slot = tick parity).  With ``use_graph`` the network and the part on B are
-    replayed from captured hipGraphs (one per head-tensor parity; the fused plan never allocates or synchronises).  With
-    sharded streams (``pipe.id_sync``) the RCCL exchange of new-track counts, ``k4_assign_ids`` and the snapshot follow
-    B's graph eagerly.  B's work for tick k is released once K1 of tick k+1 is through, so the latency-bound tail hides
+    Two HIP streams with fixed roles.  Stream A: roi / downsample / K5 motion counts (eager), then per frame group K1
+    (eager) + the detector network; stream B: per group K2/K3 -> K4 (gates decided on the device), then global ids -> D2H
+    snapshot of the track tables (slot = tick parity).  With ``use_graph`` the networks and the part on B are replayed
+    from captured hipGraphs (one per head-tensor parity; the fused plan never allocates or synchronises).  A tick shape
+    (which streams are live, their grouping) is captured after it has run eagerly once -- that eager tick sizes every
+    buffer and sets every kernel attribute outside any capture -- and ticks of another shape run eagerly.  With sharded
+    streams (``pipe.id_sync``) the RCCL exchange of new-track counts, ``k4_assign_ids`` and the snapshot follow B's graph
+    eagerly.  B's work for tick k is released once the first K1 of tick k+1 is through, so the latency-bound tail hides
     under the next network and K1 runs alone.  Same results as ``TickPipeline.tick`` (same kernels, same order per
-    stream); the pre-detector gates are host decisions per tick and are not supported here.
+    stream).  Detectors without a batched device path need the host in the loop and are not supported here.
 
     ``submit()`` enqueues one tick and returns its ticket; ``collect()`` returns ``(ticket, tables)`` of the oldest
-    outstanding tick, ``tables[slot]`` being the arrays of ``DeviceTracker.snapshot_fetch``.
+    outstanding tick, ``tables[slot]`` being the arrays of ``DeviceTracker.snapshot_fetch``; ``collect_result()`` returns
+    the :class:`TickResult` instead.  Both raise if the device reported an overflow (tracker capacity / NMS capacity).
     """
 
     def __init__(self, pipe: TickPipeline, depth: int = 2, use_graph: bool = True, overlap: bool = True):
-        if any(pipe._motion_on) or any(a.enabled for a in pipe.adaptive) or pipe.downsample_ratio < 0.999 or \
-                any(s.roi_polygons for s in pipe.streams):
-            raise NotImplementedError("PipelinedTicks runs the ungated path (motion / adaptive-fps / ROI / downsample off)")
+        if any(not hasattr(d, "predict_batch_device") for d in pipe.detectors):
+            raise NotImplementedError("PipelinedTicks needs detectors with a batched device path (temporal heads return host "
+                                      "detections: use TickPipeline.tick)")
         if depth not in (1, 2):
             raise ValueError("depth must be 1 or 2 (two snapshot slots, two head tensors)")
         self.pipe, self.depth = pipe, depth
         self.det, self.dt = pipe.detector, pipe.tracker.device_tracker
         self.world_sharded = pipe.id_sync is not None
-        self.slot = [-1] * self.dt.n_streams
-        for i in range(len(pipe.streams)):
-            self.slot[pipe.slots[i]] = i
-        self.use_graph = bool(use_graph) and self.det.engine == "fused" and self.det.half
+        fused = all(d.engine == "fused" and d.half and d._infer_fn is None for d in pipe.detectors)
+        self.use_graph = bool(use_graph) and fused
         # ``overlap=False`` keeps everything on one stream (eager only): the per-stage timing pass of bench.py
-        self.two_streams = (overlap or self.use_graph) and self.det.engine == "fused" and self.det.half   # needs the second head tensor
+        self.two_streams = (overlap or self.use_graph) and fused              # needs per-parity head tensors
         self.sA = torch.cuda.current_stream()
         self.sB = torch.cuda.Stream(device=self.det.device) if self.two_streams else self.sA
-        self._pending = [None, None]          # eager mode: (raw, meta, events) of the tick whose stream-B part is due
+        self._pending = [None, None]          # per parity: what the stream-B part of that tick needs
+        self._meta = [None, None]             # per parity: (packets, t0) for collect_result
         self._next, self._oldest = 0, 0
         self._done = [torch.cuda.Event(), torch.cuda.Event()]
         self._net_done = [torch.cuda.Event(), torch.cuda.Event()]
         self._k1_done = [torch.cuda.Event(), torch.cuda.Event()]
-        self._net_graphs, self._post_graphs = [None, None], [None, None]
         self._posted = -1                     # last tick whose stream-B part has been issued
         self.last_post = None
+        self._seen_sigs = set()               # tick shapes that have run eagerly once
+        self._cap_sig = None                  # the captured shape
+        self._net_graphs: List[List] = []     # [group][parity]
+        self._post_graphs = [None, None]
         self._captured = False
 
     # -- pieces of a tick -------------------------------------------------------------------------------------
-    def _post_part(self, raw, meta, events=None):
-        with torch.inference_mode():
-            post = self.det._postprocess_device(raw, [meta])
-        if events: events[3].record()
-        self.dt.update_from_post(self.slot, post, self.det.config.confidence_threshold)       # K4 (+F1 filter)
-        self.last_post = post
+    def _plan_of(self, det, tensor):
+        key = (int(tensor.shape[0]), int(tensor.shape[2]), int(tensor.shape[3]))
+        if key not in det._plans:
+            det._infer(tensor)                                     # builds + autotunes the plan (outside any capture)
+        return det._plans[key]
+
+    def _post_part(self, plan, raws, metas, motion, events=None):
+        """Stream-B work of one tick for every group: K2/K3 then K4 (+ filter, rescale, gates)."""
+        p = self.pipe
+        gated = p.has_gates
+        first = True
+        for gi, g in enumerate(plan.groups):
+            det = p.detectors[g.det]
+            with torch.inference_mode():
+                post = det._postprocess_device(raws[gi], [metas[gi]])
+            if events and first: events[3].record()
+            self.dt.update_from_post(p._kslot(plan, g, first), post, det.config.confidence_threshold, gated=gated, motion=motion)
+            self.last_post = post
+            first = False
+        if first:
+            self.dt.update_from_post(p._kslot(plan, None, True), None, 0.0, gated=gated, motion=motion)
 
     def _ids_and_snapshot(self, k, events=None):
-        p = self.pipe
-        if p.id_sync is None:
-            self.dt.assign_ids()
-        else:
-            n = len(p.streams)
-            self.dt.assign_ids(p.id_sync.all_gather_counts(self.dt.new_counts_tensor()[:n]), p.global_index)
+        self.pipe.assign_ids()
         if events: events[4].record()
         self.dt.snapshot_async(k & 1)
 
-    def _capture(self, frames):
-        det = self.det
-        with torch.inference_mode():
-            tensor0, meta0 = det._preprocess(frames)
-            det._infer(tensor0)                                    # builds + autotunes the plan outside any capture
-        plan = det._plans[(int(tensor0.shape[0]), int(tensor0.shape[2]), int(tensor0.shape[3]))]
+    def _capture(self, plan, tensors, metas, motion):
+        """Record the networks (per group and head-tensor parity) and the stream-B part (per parity) of a tick of this
+        shape.  Nothing executes here; every kernel of the shape has already run eagerly once."""
+        p = self.pipe
         torch.cuda.synchronize()
-        raws = [None, None]
-        for par in (0, 1):
-            plan.use_output(par)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                with torch.inference_mode():
-                    raws[par] = det._infer(tensor0)                # network only, writes head tensor `par`
-            self._net_graphs[par] = g
+        self._net_graphs = []
+        raws = [[None, None] for _ in plan.groups]
+        for gi, g in enumerate(plan.groups):
+            det = p.detectors[g.det]
+            fp = self._plan_of(det, tensors[gi])
+            pair = []
+            for par in (0, 1):
+                fp.use_output(2 * gi + par)
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr):
+                    with torch.inference_mode():
+                        raws[gi][par] = det._infer(tensors[gi])    # network only, writes head tensor (group, parity)
+                pair.append(gr)
+            self._net_graphs.append(pair)
         torch.cuda.synchronize()
         for par in (0, 1):
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._post_part(raws[par], meta0)
+            mo = None if motion is None else (p._motion_gate().counts[par], motion[1])   # the parity's K5 count row
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                self._post_part(plan, [r[par] for r in raws], metas, mo)
                 if not self.world_sharded:
                     self._ids_and_snapshot(par)                    # single GPU: ids + snapshot ride in the graph
-            self._post_graphs[par] = g
+            self._post_graphs[par] = gr
         torch.cuda.synchronize()
+        self._cap_sig = plan.signature
         self._captured = True
 
     def _issue_post(self, k, after):
@@ -290,67 +466,83 @@ class PipelinedTicks:
             self.sB.wait_event(self._net_done[par])
             if after is not None:
                 self.sB.wait_event(after)
-            if self.use_graph:
+            mode, plan, raws, metas, motion, events = self._pending[par]
+            if mode == "graph":
                 self._post_graphs[par].replay()
                 if self.world_sharded:
                     self._ids_and_snapshot(k)                      # the id exchange (RCCL) stays outside the graph
             else:
-                raw, meta, events = self._pending[par]
-                self._post_part(raw, meta, events)
+                self._post_part(plan, raws, metas, motion, events)
                 self._ids_and_snapshot(k, events)
             self._done[par].record(self.sB)
         self._posted = k
 
     # -- API ----------------------------------------------------------------------------------------------------
-    def submit(self, packets: Optional[Sequence[FramePacket]] = None, events=None, before_k1=None) -> int:
-        """Enqueue one tick.  ``events``: optional list of 5 timing events (before K1, after K1, after the network,
-        after K2/K3, after ids) -- the last three are only recorded in the non-graph path.  ``before_k1``: optional
-        callable run right before the K1 launch (bench.py arms the dispatch-level profiling events with it)."""
+    def submit(self, packets: Optional[Sequence[Optional[FramePacket]]] = None, events=None, before_k1=None,
+               process: Optional[Sequence[bool]] = None) -> int:
+        """Enqueue one tick.  ``process``: optional per-stream decisions of the caller (False = skipped frame) on top of
+        the configured gates.  ``events``: optional list of 5 timing events (before K1, after K1, after the network, after
+        K2/K3, after ids) -- the last three are only recorded in the non-graph path.  ``before_k1``: optional callable run
+        right before the first K1 launch (bench.py arms the dispatch-level profiling events with it)."""
         if self._next - self._oldest >= self.depth:
             raise RuntimeError("collect() the oldest tick first")
+        p = self.pipe
         k = self._next
         par = k & 1
+        t0 = time.perf_counter()
         if packets is None:
-            packets = [src.next_packet() for src in self.pipe.sources]
-        frames = [p.frame for p in packets]
-        if self.use_graph and not self._captured:
-            self._capture(frames)
-        with torch.inference_mode():
-            if events: events[0].record()
-            if before_k1: before_k1()
-            tensor, meta = self.det._preprocess(frames)            # K1
-            if events: events[1].record()
-        if self.two_streams:
-            self._k1_done[par].record(self.sA)
-            if k >= 2:
-                self.sA.wait_event(self._done[par])                # tick k-2 has finished reading head tensor `par`
-            if self.use_graph:
-                self._net_graphs[par].replay()
+            packets = [src.next_packet() for src in p.sources]
+        packets = p._frames_for_detection(packets)                 # roi / downsample (device work on stream A)
+        plan = p.plan_tick(packets, process)
+        motion = p._device_gates(packets, par) if p.has_gates else None       # K5 + gate parameters (no sync)
+        sig = plan.signature
+        replay = self.use_graph and self.two_streams and self._cap_sig == sig
+        capture_after = self.use_graph and self.two_streams and not replay and sig in self._seen_sigs
+        tensors, metas, raws = [], [], []
+        for gi, g in enumerate(plan.groups):
+            det = p.detectors[g.det]
+            with torch.inference_mode():
+                if events and gi == 0: events[0].record()
+                if before_k1 and gi == 0: before_k1()
+                tensor, meta = det._preprocess([packets[i].frame for i in g.idx])      # K1
+                if events and gi == 0: events[1].record()
+            if self.two_streams and gi == 0:
+                self._k1_done[par].record(self.sA)
+                if k >= 2:
+                    self.sA.wait_event(self._done[par])            # tick k-2 has finished reading the head tensors `par`
+            tensors.append(tensor); metas.append(meta)
+            if replay:
+                self._net_graphs[gi][par].replay()
             else:
                 with torch.inference_mode():
-                    plan = self.det._plans.get((int(tensor.shape[0]), int(tensor.shape[2]), int(tensor.shape[3])))
-                    if plan is None:
-                        self.det._infer(tensor)                    # builds + autotunes the plan
-                        plan = self.det._plans[(int(tensor.shape[0]), int(tensor.shape[2]), int(tensor.shape[3]))]
-                    plan.use_output(par)
-                    raw = self.det._infer(tensor)
-                if events: events[2].record()
-                self._pending[par] = (raw, meta, events)
+                    if self.two_streams:
+                        self._plan_of(det, tensor).use_output(2 * gi + par)
+                    raws.append(det._infer(tensor))
+        if events: events[2].record()
+        self._pending[par] = ("graph" if replay else "eager", plan, None if replay else raws, metas, motion,
+                              None if replay else events)
+        self._meta[par] = (packets, t0)
+        if self.two_streams:
+            if not plan.groups:
+                self._k1_done[par].record(self.sA)
             self._net_done[par].record(self.sA)
             if self.depth == 1:
                 self._issue_post(k, None)
             elif k >= 1 and self._posted < k - 1:
                 self._issue_post(k - 1, self._k1_done[par])        # K1 of this tick first, then the previous tail
         else:
-            with torch.inference_mode():
-                raw = self.det._infer(tensor)
-            if events: events[2].record()
-            self._post_part(raw, meta, events)
-            self._ids_and_snapshot(k, events)
+            _, pl, rw, mt, mo, ev = self._pending[par]
+            self._post_part(pl, rw, mt, mo, ev)
+            self._ids_and_snapshot(k, ev)
+        if capture_after:     # second tick of this shape: everything is sized and warm -> record it for the ticks to come
+            if self._posted < k:
+                self._issue_post(k, None)
+            self._capture(plan, tensors, metas, motion)
+        self._seen_sigs.add(sig)
         self._next += 1
         return k
 
-    def collect(self):
+    def _collect(self):
         if self._oldest >= self._next:
             raise RuntimeError("nothing in flight")
         k = self._oldest
@@ -361,5 +553,16 @@ class PipelinedTicks:
             tables = self.dt.snapshot_fetch(k & 1, wait=False)
         else:
             tables = self.dt.snapshot_fetch(k & 1)                 # tracks visible to the host
+        status = self.dt.snapshot_status(k & 1)
         self._oldest += 1
+        return k, tables, status
+
+    def collect(self):
+        k, tables, status = self._collect()
+        ops.DeviceTracker.raise_on_flags(status[2])
         return k, tables
+
+    def collect_result(self) -> TickResult:
+        k, tables, status = self._collect()
+        packets, t0 = self._meta[k & 1]
+        return self.pipe.finish(packets, tables, status, t0)

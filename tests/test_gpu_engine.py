@@ -16,6 +16,17 @@ from realtime_video_analytics_32streams_amd.yolov8 import build_detector_net
 pytestmark = pytest.mark.gpu
 
 
+def _assert_conv_close(got, want, res=None, what=""):
+    """fp16-ulp bound, per element.  Both sides use the same fp16 operands; the reference is fp32 throughout, the kernel
+    accumulates in fp32 (K <= 4608 terms: order effects ~1e-6 relative), rounds the activated value to fp16 once and,
+    with a residual, rounds the sum once more: |err| <= ulp(|silu|)/2 + ulp(|out|)/2 with ulp(v) = 2^-10 |v| and
+    |silu| <= |want| + |res|.  A kernel that drops a K-step, a tap or a tail channel is off by ~1e-1 here."""
+    mag = want.abs() + (res.float().abs() if res is not None else 0.0)
+    tol = 2.0 ** -10 * mag + 1e-4
+    bad = (got - want).abs() > tol
+    assert not bool(bad.any()), (what, float((got - want).abs().max()), int(bad.sum()))
+
+
 def _conv_ref(x_nhwc, w, b, k, stride, act, res=None):
     """fp32 reference on the fp16-rounded operands: x [B,H,W,Cin], w [Cout,Cin,k,k]."""
     y = F.conv2d(x_nhwc.float().permute(0, 3, 1, 2), w.float(), b.float(), stride=stride, padding=k // 2)
@@ -63,8 +74,7 @@ def test_conv_primitive_matches_fp32_reference(shape):
     torch.cuda.synchronize()
     want = _conv_ref(x, w.cuda(), b.cuda(), k, stride, act, res)
     got = out_full[..., oe:].float()
-    err = (got - want).abs().max().item()
-    assert err < 2e-2 + 2e-3 * want.abs().max().item(), err
+    _assert_conv_close(got, want, res)
     if oe:
         assert torch.all(out_full[..., :oe] == 7.0)        # the neighbouring slice is untouched
 
@@ -100,8 +110,7 @@ def test_every_conv_variant_agrees(shape):
         if rc != N.RVA_OK:
             continue
         torch.cuda.synchronize()
-        err = (out.float() - want).abs().max().item()
-        assert err < 2e-2 + 2e-3 * want.abs().max().item(), (variant, err)
+        _assert_conv_close(out.float(), want, res, variant)
         ran.append(variant)
     assert 0 in ran and len(ran) >= 3, ran
     if k == 3 and stride == 1:
@@ -135,7 +144,7 @@ def test_pool_upsample_head_primitives():
     assert torch.equal(up, out.repeat_interleave(2, 1).repeat_interleave(2, 2))
 
 
-@pytest.mark.parametrize("scale,batch", [("s", 2), ("n", 2), ("m", 1)])
+@pytest.mark.parametrize("scale,batch", [("s", 2), ("n", 2), ("m", 4)])      # m x 4 = one GPU's share of BASELINE configs[3]
 def test_fused_plan_matches_torch_module(scale, batch):
     net = build_detector_net(scale, seed=0)
     ref = copy.deepcopy(net).fuse().float().cuda()
@@ -179,8 +188,7 @@ def test_upcat_conv_matches_torch(shape):
                                      B, H, W, Cout, 1, variant, C.c_void_p(torch.cuda.current_stream().cuda_stream))
         ctx.check(rc)
         torch.cuda.synchronize()
-        err = (out.float() - want).abs().max().item()
-        assert err < 2e-2 + 2e-3 * want.abs().max().item(), (variant, err)
+        _assert_conv_close(out.float(), want, None, variant)
         ran += 1
     assert ran == 8
 
@@ -214,8 +222,7 @@ def test_patch_kernels_match_torch(shape):
     ctx.check(rc)
     torch.cuda.synchronize()
     want = _conv_ref(x, w.cuda(), b.cuda(), 3, stride, 1, res)
-    err = (out[..., 8:].float() - want).abs().max().item()
-    assert err < 2e-2 + 2e-3 * want.abs().max().item(), err
+    _assert_conv_close(out[..., 8:].float(), want, res, variant)
     assert torch.all(out[..., :8] == 7.0)
 
 

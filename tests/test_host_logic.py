@@ -202,3 +202,18 @@ def test_id_sync_world2_gloo_matches_single_process(tmp_path):
         for t, s, ids in json.load(open(tmp_path / f"ids_{r}.json")):
             got[(t, s)] = ids
     assert got == want
+
+
+def test_bench_refuses_to_run_fewer_ranks_than_asked_for():
+    """`python bench.py --gpus N` starts N ranks itself; with fewer visible devices it fails loudly instead of measuring
+    one GPU (this container has none)."""
+    import os
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs are visible")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "RVA_SHARE_GPU")}
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode != 0 and "refusing to run fewer ranks" in p.stderr and not p.stdout.strip()
