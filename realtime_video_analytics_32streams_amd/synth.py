@@ -272,3 +272,60 @@ def _new_obj(rng, W, H, n_cls):
         rng.uniform(0, W), rng.uniform(0, H), rng.uniform(30, 300), rng.uniform(30, 300),
         rng.uniform(-6, 6), rng.uniform(-4, 4), float(rng.integers(0, n_cls)),
     ])
+
+
+# --------------------------------------------------------------------------------------
+# seeded modules / clips (temporal-network goldens: oracle/gen_golden.py G6 and the tests that replay them)
+# --------------------------------------------------------------------------------------
+# reference parameter prefix -> this package's (scripts/convert_temporal_model_to_onnx.py:34-121 vs temporal.py)
+TEMPORAL_KEY_MAP = (("cnn.", "stem."), ("lstm.", "rnn."), ("fc.", "head."))
+
+
+def map_temporal_key(key: str, kind: str = "cnn_lstm") -> str:
+    """Name of a reference state-dict entry in CnnLstmNet (``cnn -> stem``, ``lstm -> rnn``, ``fc -> head``); the 3D-CNN
+    uses the reference's own names."""
+    if kind == "cnn_lstm":
+        for a, b in TEMPORAL_KEY_MAP:
+            if key.startswith(a):
+                return b + key[len(a):]
+    return key
+
+
+def seeded_module(ctor, seed: int):
+    """``ctor()`` under ``torch.manual_seed(seed)``, every BatchNorm given non-trivial seeded statistics, eval mode."""
+    import torch
+    state = torch.random.get_rng_state()
+    torch.manual_seed(seed)
+    try:
+        m = ctor()
+    finally:
+        torch.random.set_rng_state(state)
+    g = torch.Generator().manual_seed(seed + 12345)
+    for mod in m.modules():
+        if isinstance(mod, (torch.nn.BatchNorm2d, torch.nn.BatchNorm3d)):
+            mod.running_mean.copy_(torch.randn(mod.num_features, generator=g) * 0.1)
+            mod.running_var.copy_(torch.rand(mod.num_features, generator=g) * 0.5 + 0.75)
+            mod.weight.data.copy_(torch.rand(mod.num_features, generator=g) * 0.5 + 0.75)
+            mod.bias.data.copy_(torch.randn(mod.num_features, generator=g) * 0.1)
+    return m.eval()
+
+
+def seeded_clip(shape, seed: int):
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(tuple(shape), generator=g)
+
+
+def state_sha(state_dict, key_map=()) -> str:
+    """SHA-256 over (mapped name, float32 bytes) of every floating-point entry, in the reference's key order."""
+    sha = hashlib.sha256()
+    for k, v in state_dict.items():
+        if not v.is_floating_point():
+            continue                      # num_batches_tracked
+        for a, b in key_map:
+            if k.startswith(a):
+                k = b + k[len(a):]
+                break
+        sha.update(k.encode())
+        sha.update(v.detach().float().contiguous().cpu().numpy().tobytes())
+    return sha.hexdigest()

@@ -102,6 +102,14 @@ class Cnn3dNet(nn.Module):
         return self.fc(self.conv3d(x).flatten(1))
 
 
+def load_reference_state_dict(net: nn.Module, state_dict, kind: str = "cnn_lstm") -> nn.Module:
+    """Load a state dict in the REFERENCE's parameter naming (``DummyCNNLSTM``: cnn.* / lstm.* / fc.*, ``Dummy3DCNN``:
+    conv3d.* / fc.*, scripts/convert_temporal_model_to_onnx.py:34-121) into :class:`CnnLstmNet` / :class:`Cnn3dNet`."""
+    from .synth import map_temporal_key
+    net.load_state_dict({map_temporal_key(k, kind): v for k, v in state_dict.items()})
+    return net
+
+
 class _HipTemporalDetector:
     """Shared body of the temporal heads, duck-typed like the reference's (``.config`` and ``.predict(packet)``):
     clip buffering (temporal_detector.py:58-120), per-frame pre-process on arrival into an HBM ring, top-5 of the

@@ -31,3 +31,20 @@ def script_sha(script) -> str:
         for fd in row:
             sha.update(fd.boxes.tobytes()); sha.update(fd.conf.tobytes()); sha.update(fd.cls.tobytes())
     return sha.hexdigest()
+
+
+def temporal_net(case):
+    """This package's network for a G6 case, rebuilt from the seed; its state dict must hash to what the REFERENCE's
+    module (scripts/convert_temporal_model_to_onnx.py:34-121) held when the logits were recorded."""
+    from realtime_video_analytics_32streams_amd import synth
+    from realtime_video_analytics_32streams_amd.temporal import Cnn3dNet, CnnLstmNet
+    kw = case["ctor"]
+    if case["kind"] == "cnn_lstm":
+        ctor = lambda: CnnLstmNet(kw["num_classes"], kw["hidden_size"])      # noqa: E731
+    else:
+        ctor = lambda: Cnn3dNet(kw["num_classes"])                           # noqa: E731
+    net = synth.seeded_module(ctor, case["seed"])
+    assert synth.state_sha(net.state_dict()) == case["state_sha"], "torch drift: rebuilt weights differ from the reference's"
+    x = synth.seeded_clip(case["clip_shape"], case["clip_seed"])
+    assert synth.sha256_of(x.numpy()) == case["clip_sha"]
+    return net, x

@@ -8,7 +8,7 @@ import pytest
 from oracle import oracle as orc
 from realtime_video_analytics_32streams_amd import synth
 from tests.conftest import load_golden
-from tests.helpers import head_for_case, script_sha, table_digest
+from tests.helpers import head_for_case, script_sha, table_digest, temporal_net
 
 
 def _case_id(c):
@@ -147,3 +147,32 @@ def test_oracle_frame_normalisation_matches_numpy_semantics(norm, out_dtype):
     tchw = orc.preprocess_norm_frames(frames, tw, th, norm, out_dtype, layout=0)
     cthw = orc.preprocess_norm_frames(frames, tw, th, norm, out_dtype, layout=1)
     assert np.array_equal(np.transpose(tchw, (1, 0, 2, 3)), cthw) and np.array_equal(tchw[0], got)
+
+
+def test_temporal_networks_reproduce_reference_logits_on_cpu():
+    """S3 / 8f-4: CnnLstmNet and Cnn3dNet ARE the reference's DummyCNNLSTM / Dummy3DCNN -- same parameters under the key map
+    cnn->stem, lstm->rnn, fc->head, same logits for the same clip (the reference loops over frames, this package batches
+    them through the stem: fp32 reassociation only)."""
+    import torch
+    for case in load_golden("temporal_nets.json"):
+        net, x = temporal_net(case)
+        with torch.inference_mode():
+            got = net(x).numpy()
+        want = np.asarray(case["logits"], np.float32)
+        assert got.shape == want.shape
+        assert np.allclose(got, want, rtol=1e-4, atol=1e-5), (case["kind"], float(np.abs(got - want).max()))
+
+
+def test_temporal_key_map_loads_a_reference_state_dict():
+    from realtime_video_analytics_32streams_amd import synth
+    from realtime_video_analytics_32streams_amd.temporal import CnnLstmNet, load_reference_state_dict
+    net = CnnLstmNet(8, 16)
+    ref_named = {}
+    for k, v in synth.seeded_module(lambda: CnnLstmNet(8, 16), 5).state_dict().items():
+        for ours, theirs in (("stem.", "cnn."), ("rnn.", "lstm."), ("head.", "fc.")):
+            if k.startswith(ours):
+                k = theirs + k[len(ours):]
+        ref_named[k] = v
+    assert any(k.startswith("cnn.") for k in ref_named) and any(k.startswith("lstm.") for k in ref_named)
+    load_reference_state_dict(net, ref_named, "cnn_lstm")
+    assert synth.state_sha(net.state_dict()) == synth.state_sha(ref_named, synth.TEMPORAL_KEY_MAP)
