@@ -369,6 +369,34 @@ def extras(args, out, sources, rctx, dev, dcfg, tcfg):
                           "k4_us_per_tick": round(float(np.mean([e[1].elapsed_time(e[2]) for e in ev])) * 1e3, 1)}
         trk.close()
     out["post_tracker_load_sweep"] = {"streams": S, "ticks": 30, **sweep}
+    out["decode"] = decode_stage(dev)
+
+
+def decode_stage(dev):
+    """D1 as its own stage: frames/s of one rocDecode session on a local bitstream (RVA_DECODE_SAMPLE = an MP4 or Annex-B
+    file), surfaces left in HBM.  Needs librocdecode AND a file; this project's boxes have neither, so the stage reports
+    why it was not measured instead of substituting anything."""
+    from realtime_video_analytics_32streams_amd.config import StreamConfig
+    from realtime_video_analytics_32streams_amd.video_stream import RocDecodeStream, rocdecode_status
+    status = rocdecode_status()
+    sample = os.environ.get("RVA_DECODE_SAMPLE", "")
+    if not status.startswith("available"):
+        return {"measured": False, "why": "rocDecode " + status}
+    if not sample or not Path(sample).is_file():
+        return {"measured": False, "why": "librocdecode present but no bitstream: set RVA_DECODE_SAMPLE to a local H.264/H.265 file "
+                                           "(no encoder exists offline to synthesise 1080p30 H.265)"}
+    st = RocDecodeStream(StreamConfig(name="decode-bench", url=sample, warmup_seconds=0.0), device=dev.index)
+    st.open_sync()
+    n, t0 = 0, time.perf_counter()
+    while n < 2000 and time.perf_counter() - t0 < 20.0:
+        if st.next_surface() is None:
+            break
+        n += 1
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    info = dict(st.info)
+    st.close_sync()
+    return {"measured": True, "frames": n, "frames_per_s": round(n / dt, 1), "sessions": 1, "source": {k: info.get(k) for k in ("codec", "width", "height")}}
 
 
 def cpu_baseline(args, net_cpu, shifts, sources, dcfg, tcfg):

@@ -354,10 +354,35 @@ int rva_resize_nv12_to_bgr_batch(rva_ctx *ctx, const void *const *y_ptrs, const 
                                  void *out_bgr, int dst_w, int dst_h, rva_stream_t stream);
 
 /* ----------------------------------------------------------------------------------------------
- * Decode probe -- stands where VideoStream.open() (video_stream.py:61-95) sits.  librocdecode is
- * looked up with dlopen at run time; RVA_ERR_UNAVAILABLE if the machine does not have it.
+ * D1 decode -- stands where VideoStream.open()/frames() sit on cv2.VideoCapture(url, CAP_FFMPEG) (video_stream.py:76,
+ * 173): an H.264 / H.265 Annex-B elementary stream goes to the VCN decoder through rocDecode and comes back as NV12
+ * surfaces in HBM (device pointers + pitch, the input form of rva_preprocess_nv12_batch); no frame visits the host.
+ * librocdecode is looked up with dlopen at run time: rva_decode_available() / rva_decoder_create() report
+ * RVA_ERR_UNAVAILABLE on a machine that does not have it (the demuxer and the retry / back-off / reconnect policy of
+ * video_stream.py:155-243 live on the host side: mp4.py, video_stream.py of this package).
  * -------------------------------------------------------------------------------------------- */
+typedef struct rva_decoder rva_decoder;
+enum rva_codec { RVA_CODEC_H264 = 0, RVA_CODEC_HEVC = 1 };
+
 int rva_decode_available(char *detail, int detail_len);
+
+/* One decode session (parser + decoder) on ctx's device.  num_surfaces: decode surfaces to ask for (the stream's own
+ * minimum wins when larger; <= 0: 8).  8-bit 4:2:0 streams only (what maps onto NV12). */
+int rva_decoder_create(rva_ctx *ctx, int codec, int num_surfaces, rva_decoder **out);
+void rva_decoder_destroy(rva_decoder *dec);
+
+/* Feed ONE access unit (host memory, Annex-B start codes, parameter sets in band in front of sync samples); pts in
+ * 10 MHz units.  end_of_stream != 0 flushes the decoder (data may be NULL / size 0).  Decoding is submitted from inside
+ * this call (parser callbacks); decoded pictures queue up for rva_decoder_next_frame. */
+int rva_decoder_feed(rva_decoder *dec, const uint8_t *data, int size, int64_t pts, int end_of_stream);
+
+/* Next picture in display order: *pic_index >= 0 and device pointers *y / *uv (interleaved) with a common *pitch, the
+ * display size *width x *height (cropped to whole chroma pairs), or *pic_index == -1 when nothing is displayable yet
+ * (feed more data).  Waits for that picture's decode to finish.  The surface stays valid until
+ * rva_decoder_release(dec, pic_index) hands it back to the decoder's pool. */
+int rva_decoder_next_frame(rva_decoder *dec, void **y, void **uv, int32_t *pitch, int32_t *width, int32_t *height,
+                           int64_t *pts, int32_t *pic_index);
+int rva_decoder_release(rva_decoder *dec, int pic_index);
 
 #ifdef __cplusplus
 }

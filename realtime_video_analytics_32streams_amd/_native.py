@@ -18,7 +18,8 @@ PKG = Path(__file__).resolve().parent
 ROOT = PKG.parent
 CSRC = PKG / "csrc"
 LIB_PATH = PKG / "librva.so"
-SOURCES = ["rva_ctx.hip", "rva_preprocess.hip", "rva_postprocess.hip", "rva_tracker.hip", "rva_conv.hip", "rva_gates.hip"]
+SOURCES = ["rva_ctx.hip", "rva_preprocess.hip", "rva_postprocess.hip", "rva_tracker.hip", "rva_conv.hip", "rva_gates.hip",
+           "rva_decode.hip"]
 # -ffp-contract=off: parity kernels must not fuse a*b+c (SURVEY.md hard part 4)
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off",
                "-Wall", "-Wno-unused-function"]
@@ -28,6 +29,7 @@ RVA_F16, RVA_F32, RVA_F64 = 0, 1, 2
 NORM_IMAGENET_F32, NORM_VIDEO_F32, NORM_IMAGENET_F64 = 0, 1, 2      # enum rva_frame_norm
 LAYOUT_NCHW, LAYOUT_CNHW = 0, 1                                    # enum rva_frame_layout
 RVA_MAX_BATCH = 64
+RVA_CODEC_H264, RVA_CODEC_HEVC = 0, 1
 
 
 class Letterbox(C.Structure):
@@ -123,6 +125,11 @@ def lib() -> C.CDLL:
         "rva_tracker_state": (C.c_int, [_P, i64p, C.POINTER(C.c_int), _P]),
         "rva_tracker_set_next_id": (C.c_int, [_P, C.c_int64, _P]),
         "rva_decode_available": (C.c_int, [C.c_char_p, C.c_int]),
+        "rva_decoder_create": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(_P)]),
+        "rva_decoder_destroy": (None, [_P]),
+        "rva_decoder_feed": (C.c_int, [_P, C.c_char_p, C.c_int, C.c_int64, C.c_int]),
+        "rva_decoder_next_frame": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), i32p, i32p, i32p, i64p, i32p]),
+        "rva_decoder_release": (C.c_int, [_P, C.c_int]),
         "rva_motion_nv12_batch": (C.c_int, [_P, pp, pp, i32p, pp, pp, C.c_int, C.c_int, C.c_int, _P, _P]),
         "rva_motion_nv12_masked_batch": (C.c_int, [_P, pp, pp, i32p, pp, pp, pp, C.c_int, C.c_int, C.c_int, _P, _P]),
         "rva_motion_bgr_batch": (C.c_int, [_P, pp, i32p, pp, pp, C.c_int, C.c_int, C.c_int, _P, _P]),
@@ -164,7 +171,8 @@ EXPORTS = [
     "rva_tracker_set_gates", "rva_tracker_snapshot_status", "rva_tracker_new_counts",
     "rva_tracker_assign_ids", "rva_tracker_read", "rva_tracker_read_all", "rva_tracker_snapshot_async",
     "rva_tracker_snapshot_fetch", "rva_tracker_state",
-    "rva_tracker_set_next_id", "rva_decode_available", "rva_motion_nv12_batch", "rva_motion_nv12_masked_batch", "rva_motion_bgr_batch",
+    "rva_tracker_set_next_id", "rva_decode_available", "rva_decoder_create", "rva_decoder_destroy", "rva_decoder_feed",
+    "rva_decoder_next_frame", "rva_decoder_release", "rva_motion_nv12_batch", "rva_motion_nv12_masked_batch", "rva_motion_bgr_batch",
     "rva_preprocess_nv12_masked_batch", "rva_resize_nv12_to_bgr_batch", "rva_tracker_set_box_scale", "rva_conv_cout_pad", "rva_conv_num_variants", "rva_conv2d_nhwc_f16", "rva_conv2d_nhwc_f16_v", "rva_stem_conv_f16",
     "rva_conv1x1_head_f16", "rva_conv1x1_upcat_f16", "rva_sppf_pool3_nhwc_f16", "rva_maxpool5_nhwc_f16", "rva_upsample2x_nhwc_f16", "rva_yolo_head_f16", "rva_yolo_head3_f16",
 ]

@@ -1,6 +1,4 @@
 // Context, geometry and scratch management of librva (host side only; no kernels here).
-#include <dlfcn.h>
-
 #include <cmath>
 #include <cstring>
 #include <mutex>
@@ -118,22 +116,6 @@ int rva_letterbox_meta(int src_w, int src_h, int dst_w, int dst_h, rva_letterbox
     out->pad_left = (dst_w - out->new_w) / 2;
     out->pad_top = (dst_h - out->new_h) / 2;
     return RVA_OK;
-}
-
-int rva_decode_available(char *detail, int detail_len)
-{
-    const char *names[] = {"librocdecode.so", "librocdecode.so.0", "librocdecode.so.1", "/opt/rocm/lib/librocdecode.so"};
-    for (const char *nm : names) {
-        void *h = dlopen(nm, RTLD_LAZY | RTLD_LOCAL);
-        if (h) {
-            bool ok = dlsym(h, "rocDecCreateDecoder") && dlsym(h, "rocDecDecodeFrame") && dlsym(h, "rocDecGetVideoFrame");
-            if (detail && detail_len > 0) snprintf(detail, detail_len, "%s %s", nm, ok ? "ok" : "missing symbols");
-            dlclose(h);
-            return ok ? RVA_OK : RVA_ERR_UNAVAILABLE;
-        }
-    }
-    if (detail && detail_len > 0) snprintf(detail, detail_len, "librocdecode.so not found (%s)", dlerror() ? "dlopen failed" : "");
-    return RVA_ERR_UNAVAILABLE;
 }
 
 }  // extern "C"

@@ -217,3 +217,150 @@ def test_bench_refuses_to_run_fewer_ranks_than_asked_for():
     p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert p.returncode != 0 and "refusing to run fewer ranks" in p.stderr and not p.stdout.strip()
+
+
+def test_capture_loop_matches_reference_recording():
+    """_BaseStream.frames(): retry / back-off / reconnect / pacing against the event traces recorded from the reference's
+    own VideoStream.frames() (tests/golden/capture_loop.json; oracle/gen_golden.py drives it with a scripted capture)."""
+    import asyncio
+    from realtime_video_analytics_32streams_amd.video_stream import _BaseStream
+
+    class Stop(Exception):
+        pass
+
+    for case in load_golden("capture_loop.json"):
+        events, opens, reads = [], list(case["opens"]), list(case["reads"])
+
+        def rec(*e):
+            events.append(list(e))
+            if len(events) >= case["cap"]:
+                raise Stop()
+
+        class Scripted(_BaseStream):
+            def open_sync(self):
+                ok = bool(opens.pop(0)) if opens else False
+                rec("open", int(ok))
+                if not ok:
+                    raise RuntimeError(f"Unable to open stream {self.config.name}")
+                super().open_sync()
+
+            def close_sync(self):
+                rec("close")
+                super().close_sync()
+
+            def next_surface(self):
+                if not reads:
+                    raise Stop()
+                return "frame" if reads.pop(0) == "1" else None
+
+        async def drive():
+            st = Scripted(C.StreamConfig(name="cam", url="rtsp://x", **case["cfg"]))
+
+            async def fake_sleep(t):
+                rec("sleep", float(t))
+            st._sleep = fake_sleep
+            try:
+                async for pkt in st.frames():
+                    rec("frame", pkt.frame_id)
+                return "ended"
+            except Stop:
+                return "stopped"
+            except RuntimeError as exc:
+                return f"RuntimeError: {exc}"
+        result = asyncio.run(drive())
+        assert events == case["events"], case["name"]
+        assert result == case["result"], case["name"]
+
+
+def test_mp4_demuxer_on_the_reference_sample():
+    """MP4 -> Annex-B on the one real bitstream that exists offline (the reference's data/samples/demo.mp4; read in place,
+    never copied; absent on the GPU box -> skipped there).  Facts from SURVEY.md section 2 #23: H.264 High@L3.0, 640x360,
+    400 frames at 30000/1001 fps."""
+    from realtime_video_analytics_32streams_amd import mp4
+    sample = Path("/root/reference/data/samples/demo.mp4")
+    if not sample.exists():
+        pytest.skip("reference sample not present on this machine")
+    with mp4.Mp4Demuxer(sample) as d:
+        info = d.describe()
+        assert (info["codec"], info["entry"], info["width"], info["height"], info["samples"]) == ("h264", "avc1", 640, 360, 400)
+        assert info["fps"] == (30000, 1001) and info["nal_length_size"] == 4
+        sps = info["sps"]
+        assert (sps["profile_idc"], sps["level_idc"], sps["width"], sps["height"]) == (100, 30, 640, 360)
+        assert (sps["coded_width"], sps["coded_height"]) == (640, 368)          # 23 macroblock rows, 8 cropped
+        n_idr = n_bytes = 0
+        last_pts = -1
+        for i, (au, pts, sync) in enumerate(d.access_units()):
+            types = [n[0] & 0x1F for n in mp4.iter_annexb_nals(au)]
+            assert au.startswith(mp4.START_CODE) and types, i
+            if sync:
+                assert types[:2] == [7, 8] and 5 in types, (i, types)              # SPS, PPS re-inserted in front of the IDR
+                n_idr += 1
+            else:
+                assert 5 not in types and 7 not in types
+            assert all(t in (1, 5, 6, 7, 8, 9) for t in types)
+            n_bytes += len(au)
+            last_pts = max(last_pts, pts)
+        assert i == 399 and n_idr == len(d.track.sync) >= 1
+        assert n_bytes == sum(d.track.sizes) + n_idr * len(d.parameter_sets_annexb())  # 4-byte lengths -> 4-byte start codes
+        assert abs(last_pts / 1e7 - 399 * 1001 / 30000) < 0.2                       # ~13.3 s of 10 MHz timestamps
+
+
+def test_mp4_demuxer_synthetic_hevc_and_errors():
+    """A hand-built MP4 (hvc1, 2-byte NAL lengths, co64, two chunks) exercises the paths demo.mp4 does not."""
+    import struct
+    from realtime_video_analytics_32streams_amd import mp4
+
+    def box(t, payload):
+        return struct.pack(">I4s", 8 + len(payload), t) + payload
+
+    def full(t, payload, ver=0):
+        return box(t, bytes([ver, 0, 0, 0]) + payload)
+    vps, sps, pps = b"\x40\x01\xaa", b"\x42\x01\xbb\xcc", b"\x44\x01\xdd"
+    arrays = b"".join(bytes([0x80 | typ]) + struct.pack(">HH", 1, len(ps)) + ps for typ, ps in ((32, vps), (33, sps), (34, pps)))
+    hvcc = box(b"hvcC", bytes(21) + bytes([0xFC | 1, 3]) + arrays)                  # lengthSizeMinusOne = 1
+    entry = struct.pack(">I4s", 8 + 78 + len(hvcc), b"hvc1") + bytes(24) + struct.pack(">HH", 1920, 1080) + bytes(50) + hvcc
+    nal = lambda t, n: struct.pack(">H", n) + bytes([t << 1, 1]) + bytes(range(n - 2))   # noqa: E731
+    samples = [nal(19, 9) + nal(39, 4), nal(1, 6), nal(1, 5)]
+    mdat_payload = b"".join(samples)
+    stbl = box(b"stbl", full(b"stsd", struct.pack(">I", 1) + entry) + full(b"stts", struct.pack(">III", 1, 3, 3000)) +
+               full(b"stsc", struct.pack(">IIIIIII", 2, 1, 2, 1, 2, 1, 1)) +
+               full(b"stsz", struct.pack(">II", 0, 3) + struct.pack(">III", *map(len, samples))) +
+               full(b"stss", struct.pack(">II", 1, 1)) + full(b"co64", struct.pack(">IQQ", 2, 0, 0)))
+    mdia = box(b"mdia", full(b"mdhd", struct.pack(">IIII", 0, 0, 90000, 9000) + bytes(4)) +
+               full(b"hdlr", bytes(4) + b"vide" + bytes(13)) + box(b"minf", stbl))
+    moov = box(b"moov", box(b"trak", mdia))
+    head = box(b"ftyp", b"isom" + bytes(4)) + moov
+    base = len(head) + 8
+    offs = struct.pack(">IQQ", 2, base, base + len(samples[0]) + len(samples[1]))
+    blob = (head + box(b"mdat", mdat_payload)).replace(struct.pack(">IQQ", 2, 0, 0), offs)
+    d = mp4.Mp4Demuxer(blob)
+    assert d.track.codec == "hevc" and d.track.nal_length_size == 2 and d.track.n_samples == 3 and d.track.fps == (30, 1)
+    aus = list(d.access_units())
+    assert [s for _, _, s in aus] == [True, False, False]
+    assert aus[0][0] == b"".join(mp4.START_CODE + p for p in (vps, sps, pps)) + mp4.START_CODE + samples[0][2:11] + mp4.START_CODE + samples[0][13:]
+    assert aus[2][0] == mp4.START_CODE + samples[2][2:] and aus[2][1] == 6000 * 10_000_000 // 90000
+    with pytest.raises(mp4.Mp4Error):
+        mp4.Mp4Demuxer(box(b"ftyp", b"isom") + box(b"moov", b""))
+    with pytest.raises(mp4.Mp4Error):
+        mp4.length_prefixed_to_annexb(b"\x00\x00\x00\x09abc", 4)
+
+
+def test_rocdecode_stream_fails_like_an_unopenable_capture():
+    """Without librocdecode (this image, and the GPU boxes) open() raises the reference's 'Unable to open stream' RuntimeError
+    and names the cause; the raw Annex-B splitter is host code and is checked on demo.mp4's own elementary stream."""
+    import asyncio
+    from realtime_video_analytics_32streams_amd import _native as N
+    from realtime_video_analytics_32streams_amd import mp4
+    from realtime_video_analytics_32streams_amd.video_stream import RocDecodeStream, _annexb_access_units, open_stream, rocdecode_status
+    st = open_stream(C.StreamConfig(name="door", url="/nonexistent/clip.mp4", warmup_seconds=0.0))
+    assert isinstance(st, RocDecodeStream)
+    if not rocdecode_status().startswith("available"):
+        with pytest.raises(RuntimeError, match="Unable to open stream door: rocDecode unavailable"):
+            asyncio.run(st.open())
+    sample = Path("/root/reference/data/samples/demo.mp4")
+    if sample.exists():
+        with mp4.Mp4Demuxer(sample) as d:
+            es = b"".join(au for au, _, _ in d.access_units())          # the file's elementary stream as one Annex-B blob
+            want = [au for au, _, _ in d.access_units()]
+        got = [au for au, _, _ in _annexb_access_units(es, N.RVA_CODEC_H264)]
+        assert len(got) == 400 and got == want                          # same access-unit boundaries as the container's samples
