@@ -225,6 +225,68 @@ def variant_from_path(model_path: str) -> str:
     return "n"
 
 
+# Ultralytics layer index (yolov8.yaml: backbone 0-9, head 10-22; 10/11/13/14/17/20 are Upsample / Concat without
+# parameters) -> attribute of YoloV8.  Inside a layer the two code bases use the same names (conv / bn, cv1 / cv2 / m.N).
+_ULTRALYTICS_LAYERS = {0: "b0", 1: "b1", 2: "b2", 3: "b3", 4: "b4", 5: "b5", 6: "b6", 7: "b7", 8: "b8", 9: "b9",
+                       12: "h12", 15: "h15", 16: "h16", 18: "h18", 19: "h19", 21: "h21"}
+
+
+def map_ultralytics_state_dict(sd, net: "YoloV8") -> dict:
+    """Rename an Ultralytics-style YOLOv8 state dict (``model.N...`` keys, ``model.22.cv2`` = box branch, ``.cv3`` = class
+    branch, ``.dfl`` = the fixed 0..15 projection) to this module's names, with a shape check against ``net``.  Accepts
+    the dict of ``YOLO(...).model.state_dict()`` (``model.N.*``) or of its inner ``nn.Sequential`` (``N.*``).  A ``.pt``
+    checkpoint of that project is a pickled module, which ``torch.load(weights_only=True)`` rightly refuses: export the
+    state dict once with the original tooling and hand THAT file to ``model_path``."""
+    own = net.state_dict()
+    out = {}
+    for key, val in sd.items():
+        k = key
+        while k.startswith("model."):
+            k = k[len("model."):]
+        idx, _, rest = k.partition(".")
+        if not idx.isdigit():
+            raise KeyError(f"'{key}' is not an Ultralytics YOLOv8 parameter name (expected model.<layer>....)")
+        i = int(idx)
+        if i == 22:
+            branch, _, tail = rest.partition(".")
+            if branch == "dfl":
+                if tuple(val.shape) != (1, 16, 1, 1) or not torch.equal(val.flatten().float(), torch.arange(16.0)):
+                    raise ValueError("model.22.dfl is not the fixed 0..15 projection this head computes in closed form")
+                continue
+            if branch not in ("cv2", "cv3"):
+                raise KeyError(f"unknown detect-head entry '{key}'")
+            new = ("detect.box." if branch == "cv2" else "detect.cls.") + tail
+        elif i in _ULTRALYTICS_LAYERS:
+            new = _ULTRALYTICS_LAYERS[i] + "." + rest
+        else:
+            raise KeyError(f"'{key}': layer {i} has no parameters in YOLOv8 (Upsample / Concat)")
+        if new.endswith("num_batches_tracked") and new not in own:
+            continue
+        if new not in own:
+            raise KeyError(f"'{key}' -> '{new}' does not exist in YOLOv8{net.scale} (wrong model scale?)")
+        if tuple(own[new].shape) != tuple(val.shape):
+            raise ValueError(f"'{key}': shape {tuple(val.shape)} does not fit YOLOv8{net.scale}'s {new} {tuple(own[new].shape)}")
+        out[new] = val
+    missing = [k for k in own if k not in out and not k.endswith("num_batches_tracked")]
+    if missing:
+        raise KeyError(f"state dict lacks {len(missing)} parameters of YOLOv8{net.scale}, e.g. {missing[:3]}")
+    return out
+
+
+def load_detector_state_dict(net: "YoloV8", sd) -> "YoloV8":
+    """This module's own naming, or Ultralytics naming (detected by its ``model.N`` / ``N`` layer-index keys)."""
+    first = next(iter(sd))
+    k = first
+    while k.startswith("model."):
+        k = k[len("model."):]
+    if k.split(".", 1)[0].isdigit():
+        sd = map_ultralytics_state_dict(sd, net)
+        net.load_state_dict(sd, strict=False)        # only num_batches_tracked may be absent
+    else:
+        net.load_state_dict(sd)
+    return net
+
+
 def build_detector_net(scale: str = "s", seed: int = 0, weights: Optional[str] = None, nc: int = 80) -> YoloV8:
     """Seeded random-init network (torch.manual_seed(seed), BN statistics randomised so that the
     folded convs are not trivial), or a local state-dict when ``weights`` names an existing file
@@ -243,8 +305,8 @@ def build_detector_net(scale: str = "s", seed: int = 0, weights: Optional[str] =
     finally:
         torch.random.set_rng_state(state)
     if weights and Path(weights).is_file():
-        sd = torch.load(weights, map_location="cpu", weights_only=True)
-        net.load_state_dict(sd)
+        sd = torch.load(weights, map_location="cpu", weights_only=True)     # never unpickles code
+        load_detector_state_dict(net, sd)
     net.eval()
     return net
 

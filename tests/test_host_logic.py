@@ -364,3 +364,40 @@ def test_rocdecode_stream_fails_like_an_unopenable_capture():
             want = [au for au, _, _ in d.access_units()]
         got = [au for au, _, _ in _annexb_access_units(es, N.RVA_CODEC_H264)]
         assert len(got) == 400 and got == want                          # same access-unit boundaries as the container's samples
+
+
+def test_ultralytics_named_state_dict_loads(tmp_path):
+    """model_path may name a state dict in the original YOLOv8 project's key naming (model.N.*, head = model.22.cv2/cv3/dfl):
+    a synthetic dict in that naming -- this module's seeded weights renamed backwards -- must load to the same network."""
+    import torch
+    from realtime_video_analytics_32streams_amd import yolov8 as Y
+    src = Y.build_detector_net("n", seed=4)
+    inv = {v: k for k, v in Y._ULTRALYTICS_LAYERS.items()}
+    theirs = {}
+    for k, v in src.state_dict().items():
+        head, _, rest = k.partition(".")
+        if head == "detect":
+            branch, _, tail = rest.partition(".")
+            theirs[f"model.22.{'cv2' if branch == 'box' else 'cv3'}.{tail}"] = v
+        else:
+            theirs[f"model.{inv[head]}.{rest}"] = v
+    theirs["model.22.dfl.conv.weight"] = torch.arange(16.0).view(1, 16, 1, 1)
+    assert "model.2.m.0.cv1.conv.weight" in theirs and "model.22.cv3.2.2.bias" in theirs and "model.9.cv2.bn.running_var" in theirs
+    f = tmp_path / "yolov8n-state.pt"
+    torch.save(theirs, f)
+    dst = Y.build_detector_net("n", seed=99, weights=str(f))          # goes through torch.load(weights_only=True)
+    a, b = src.state_dict(), dst.state_dict()
+    assert all(torch.equal(a[k], b[k]) for k in a if not k.endswith("num_batches_tracked"))
+    x = torch.rand(1, 3, 64, 64)
+    with torch.inference_mode():
+        assert torch.equal(src(x), dst(x))
+    inner = {k[len("model."):]: v for k, v in theirs.items()}           # the inner nn.Sequential's naming works too
+    Y.load_detector_state_dict(Y.build_detector_net("n", seed=5), inner)
+    with pytest.raises(ValueError, match="does not fit"):
+        Y.load_detector_state_dict(Y.build_detector_net("s", seed=5), theirs)      # an n dict into an s network
+    bad = dict(theirs); bad["model.22.dfl.conv.weight"] = torch.ones(1, 16, 1, 1)
+    with pytest.raises(ValueError, match="dfl"):
+        Y.load_detector_state_dict(Y.build_detector_net("n", seed=5), bad)
+    del bad["model.22.dfl.conv.weight"], bad["model.0.conv.weight"]
+    with pytest.raises(KeyError, match="lacks"):
+        Y.load_detector_state_dict(Y.build_detector_net("n", seed=5), bad)
