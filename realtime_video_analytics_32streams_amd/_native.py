@@ -94,6 +94,8 @@ def lib() -> C.CDLL:
         "rva_letterbox_meta": (C.c_int, [C.c_int] * 4 + [C.POINTER(Letterbox)]),
         "rva_preprocess_nv12_batch": (C.c_int, [_P, pp, pp, i32p, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int,
                                                 C.c_int, C.POINTER(Letterbox), _P]),
+        "rva_preprocess_nv12_content_batch": (C.c_int, [_P, pp, pp, i32p, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int,
+                                                        C.c_int, C.POINTER(Letterbox), _P]),
         "rva_preprocess_bgr_batch": (C.c_int, [_P, pp, i32p, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int,
                                                C.POINTER(Letterbox), _P]),
         "rva_preprocess_clip_nv12_batch": (C.c_int, [_P, pp, pp, i32p, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int,
@@ -165,7 +167,7 @@ def lib() -> C.CDLL:
 
 EXPORTS = [
     "rva_abi_version", "rva_create", "rva_destroy", "rva_last_error", "rva_reserve", "rva_letterbox_meta",
-    "rva_preprocess_nv12_batch", "rva_preprocess_bgr_batch", "rva_preprocess_clip_nv12_batch",
+    "rva_preprocess_nv12_batch", "rva_preprocess_nv12_content_batch", "rva_preprocess_bgr_batch", "rva_preprocess_clip_nv12_batch",
     "rva_preprocess_clip_bgr_batch", "rva_profile_next_preprocess", "rva_preprocess_frames_nv12_batch", "rva_preprocess_frames_bgr_batch", "rva_postprocess_batch", "rva_post_status", "rva_tracker_create",
     "rva_tracker_destroy", "rva_tracker_update_f32", "rva_tracker_update_f64", "rva_tracker_update_gated_f32",
     "rva_tracker_set_gates", "rva_tracker_snapshot_status", "rva_tracker_new_counts",

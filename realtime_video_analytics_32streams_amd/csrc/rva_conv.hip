@@ -1074,6 +1074,24 @@ typedef __attribute__((address_space(3))) void *lds_vptr;
 typedef const __attribute__((address_space(1))) void *glb_vptr;
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// One 1 KiB LDS-DMA piece: 64 lanes x 16 bytes from  sbase + voff  (wave-uniform 64-bit base in an SGPR pair, per-lane
+// 32-bit byte offset in ONE VGPR) to LDS address m0v + 16 * lane.  Written as asm so that the address really takes the
+// saddr form: through the builtin every piece cost a v_mad_i64_i32, three 64-bit VALU adds, a v_readfirstlane and the
+// scalar division that recovers (tap, chunk) from the step number -- ~100 issue cycles per piece, 650-830 cycles per K-step
+// of a wave (profiles/r01_conv_big.txt), during which its SIMD partner's MFMAs share the VALU port.  In this form a piece
+// is two scalar moves and the load; the per-lane offsets are computed once per kernel.
+__device__ __forceinline__ void lds_dma16(unsigned voff, const void *sbase, unsigned m0v)
+{
+    // "s" operands must really be scalar registers: inline asm does not legalise a VGPR into an SGPR operand.  readfirstlane
+    // is free for values the compiler already knows to be uniform and repairs the ones it does not.
+    const unsigned long long b = (unsigned long long)(size_t)sbase;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    const unsigned long long sb = ((unsigned long long)hi << 32) | lo;
+    const unsigned m0s = __builtin_amdgcn_readfirstlane(m0v);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sb), "s"(m0s) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(size_t)(lds_vptr)p; }
 __device__ __forceinline__ void wait_vm_n(int n)
 {
     switch (n) {   // wave-uniform
@@ -1104,7 +1122,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NSLOT 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __half *ring = (__half *)smem;                        // [NSLOT][PIECES][16][32]
 
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wv % WGM, wn = wv / WGM;
     const int n_tile = blockIdx.x % a.n_tiles, m_tile = blockIdx.x / a.n_tiles;
     const int P0 = m_tile * BM, n0 = n_tile * BN;
@@ -1113,45 +1132,69 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NSLOT 
     const int nsteps = 3 * cpt;
     const int wrow = 9 * a.Cin;
 
-    // this wave's pieces: idx = wv + 8k.  Per-lane constants of each piece.
+    // this wave's pieces: idx = wv + 8k.  Per-lane byte offsets of each piece, fixed for the whole kernel (see lds_dma16):
+    // activation pieces: the lane's source row for dy = 0 / 1 / 2 (clamped into the tensor) + its swizzled chunk, relative to
+    // a.in; weight pieces: the lane's weight row (tap dy = 0, chunk 0) + chunk, relative to a.w.  The per-step part of the
+    // address -- channel chunk, vertical tap -- is wave-uniform and lives in the scalar base.
     const int lrow = lane >> 2, lp = lane & 3;
-    int prow[NP];        // activation pieces: row in the run; weight pieces: element offset of the source row (tap dy=0, chunk 0)
-    int pc8[NP];         // source 16-byte chunk (swizzle inverse) * 8 halfs
     const int my_pieces = (PIECES - wv + 7) / 8;
+    unsigned poff0[NP], poff1[NP], poff2[NP];     // three 1-D arrays with compile-time indices: they must stay in registers
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
         const int idx = wv + 8 * k;
         if (idx < APIECES) {
             const int r = idx * 16 + lrow;
-            prow[k] = r;
-            pc8[k] = ((lp - 2 * (r >> 2)) & 3) * 8;
+            const unsigned c = (unsigned)(((lp - 2 * (r >> 2)) & 3) * 16);
+            const int q1 = P0 - 1 + r;
+            poff0[k] = (unsigned)min(max(q1 - a.W, 0), a.M - 1) * (unsigned)(a.ldi * 2) + c;
+            poff1[k] = (unsigned)min(max(q1, 0), a.M - 1) * (unsigned)(a.ldi * 2) + c;
+            poff2[k] = (unsigned)min(max(q1 + a.W, 0), a.M - 1) * (unsigned)(a.ldi * 2) + c;
         } else {
             const int rw = (idx - APIECES) * 16 + lrow;
             const int dx = rw / BN, co = min(n0 + rw - dx * BN, a.CoutPad - 1);
-            prow[k] = co * wrow + dx * a.Cin;
-            pc8[k] = ((lp - 2 * (rw >> 2)) & 3) * 8;
+            poff0[k] = (unsigned)(co * wrow + dx * a.Cin) * 2u + (unsigned)(((lp - 2 * (rw >> 2)) & 3) * 16);
+            poff1[k] = poff2[k] = poff0[k];
         }
     }
-    // one 1 KiB LDS-DMA piece of step s (k-th piece of this wave)
-    auto issue_piece = [&](int s, int k) {
-        const int idx = wv + 8 * k;
-        if (idx < PIECES) {
-            const int dy = s / cpt, cc = s - dy * cpt;
-            __half *slot = ring + (size_t)(s % NSLOT) * SLOTH;
-            const __half *src;
-            if (idx < APIECES) {
-                const int q = min(max(P0 + (dy - 1) * a.W - 1 + prow[k], 0), a.M - 1);
-                src = a.in + (size_t)q * a.ldi + (cc << 5) + pc8[k];
-            } else {
-                src = a.w + (size_t)(prow[k] + dy * 3 * a.Cin + (cc << 5) + pc8[k]);
-            }
-            __builtin_amdgcn_global_load_lds((glb_vptr)src, (lds_vptr)(slot + idx * 512), 16, 0, 0);
-        }
-    };
-    auto issue = [&](int s) {
-#pragma unroll
-        for (int k = 0; k < NP; ++k) issue_piece(s, k);
-    };
+    const unsigned ring0 = lds_addr(ring);
+    // the step whose pieces are issued next: every wave issues the steps in order, each exactly once.  Plain scalars and
+    // macros on purpose: as lambdas capturing this mutable state by reference the closure went to scratch memory.
+    int is_dy = 0, is_cc = 0, is_slot = 0;
+    const char *is_abase = (const char *)a.in, *is_wbase = (const char *)a.w;
+    unsigned is_lds = ring0;
+#define BIG_ISSUE_PIECE(k_)                                                                                   \
+    do {                                                                                                      \
+        const int idx_ = wv + 8 * (k_);                                                                       \
+        if (idx_ < PIECES) {                                                                                  \
+            const unsigned m0v_ = is_lds + (unsigned)idx_ * 1024u;                                            \
+            if (idx_ < APIECES) {                                                                             \
+                unsigned v_ = poff1[k_];                                                                      \
+                if (is_dy == 0) v_ = poff0[k_];                                                               \
+                if (is_dy == 2) v_ = poff2[k_];                                                               \
+                lds_dma16(v_, is_abase, m0v_);                                                                \
+            } else {                                                                                          \
+                lds_dma16(poff0[k_], is_wbase, m0v_);                                                         \
+            }                                                                                                 \
+        }                                                                                                     \
+    } while (0)
+#define BIG_ISSUE_ADVANCE()                                                                                   \
+    do {                                                                                                      \
+        ++is_cc;                                                                                              \
+        if (is_cc == cpt) { is_cc = 0; ++is_dy; }                                                             \
+        ++is_slot;                                                                                            \
+        if (is_slot == NSLOT) is_slot = 0;                                                                    \
+        is_cc = __builtin_amdgcn_readfirstlane(is_cc);       /* keep the issue state in scalar registers */   \
+        is_dy = __builtin_amdgcn_readfirstlane(is_dy);                                                        \
+        is_slot = __builtin_amdgcn_readfirstlane(is_slot);                                                    \
+        is_abase = (const char *)a.in + is_cc * 64;                                                           \
+        is_wbase = (const char *)a.w + (size_t)(is_dy * 3 * a.Cin + is_cc * 32) * 2;                         \
+        is_lds = ring0 + (unsigned)is_slot * (unsigned)(SLOTH * 2);                                           \
+    } while (0)
+#define BIG_ISSUE()                                                                                           \
+    do {                                                                                                      \
+        _Pragma("unroll") for (int k_i = 0; k_i < NP; ++k_i) BIG_ISSUE_PIECE(k_i);                            \
+        BIG_ISSUE_ADVANCE();                                                                                  \
+    } while (0)
 
     // 9-bit tap validity per pixel fragment: bit dy*3+dx set when tap (dy,dx) of that pixel lies inside its image
     int vm[FM];
@@ -1189,7 +1232,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NSLOT 
     STAMP(0);
 #pragma unroll
     for (int t = 0; t < NSLOT - 1; ++t)
-        if (t < nsteps) issue(t);
+        if (t < nsteps) BIG_ISSUE();
     STAMP(1);
     for (int s = 0; s < nsteps; ++s) {
         // retire this wave's pieces of step s (with three slots those of step s+1 stay in flight), then meet the
@@ -1205,7 +1248,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NSLOT 
         // their DMA burst before the MFMAs and the upper four after them -- while one wave of a SIMD is busy issuing
         // (~750 cycles), the other one keeps the matrix core fed
         const bool early = wv < 4;
-        if (NSLOT == 3 && more && early) issue(sn);
+        if (NSLOT == 3 && more && early) BIG_ISSUE();
         STAMP(4);
         const int dy = s / cpt;
         const __half *ab = ring + (size_t)(s % NSLOT) * SLOTH;
@@ -1251,13 +1294,14 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NSLOT 
                     for (int j = 0; j < FM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bf[0][j], acc[i][j], 0, 0, 0);
                     // two slots (2-3 blocks per CU): one LDS-DMA piece of the next step per MFMA group
                     if (dx * FN + i < NP) {
-                        if (more) issue_piece(sn, dx * FN + i);
+                        if (more) BIG_ISSUE_PIECE(dx * FN + i);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
             }
         }
-        if (NSLOT == 3 && more && !early) issue(sn);
+        if (NSLOT == 3 && more && !early) BIG_ISSUE();
+        if (NSLOT == 2 && more) BIG_ISSUE_ADVANCE();
         STAMP(5);
     }
     __syncthreads();     // all waves done with the ring: reuse it as the output staging tile
@@ -1305,6 +1349,10 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NSLOT 
     STAMP(6);
 }
 
+#undef BIG_ISSUE
+#undef BIG_ISSUE_ADVANCE
+#undef BIG_ISSUE_PIECE
+
 template <int BM, int BN, int WGM, int WGN, int NSLOT>
 hipError_t launch_big(BigArgs &a, hipStream_t s)
 {
@@ -1313,6 +1361,8 @@ hipError_t launch_big(BigArgs &a, hipStream_t s)
     constexpr size_t smem = ring > st ? ring : st;
     static_assert(smem <= 160 * 1024, "LDS budget");
     if (a.Cin % 32 || a.CoutPad % 4) return hipErrorInvalidValue;
+    // LDS-DMA addresses are a 64-bit scalar base + a 32-bit per-lane byte offset
+    if ((size_t)a.M * a.ldi * 2 >= (1ull << 32) || (size_t)a.CoutPad * 9 * a.Cin * 2 >= (1ull << 32)) return hipErrorInvalidValue;
     if (hipError_t e = rva_func_smem((const void *)k_conv3_big<BM, BN, WGM, WGN, NSLOT>, smem); e != hipSuccess) return e;
     a.n_tiles = rva_ceil_div(a.Cout, BN);
     k_conv3_big<BM, BN, WGM, WGN, NSLOT><<<rva_ceil_div(a.M, BM) * a.n_tiles, 512, smem, s>>>(a);
@@ -1359,55 +1409,79 @@ __global__ void __launch_bounds__(512)
     const int lrow = lane / LPR, lp = lane % LPR;
     // source chunk of this lane = inverse of the LDS swizzle (BK 64: chunk ^ (row & 7); BK 32: swz32's rotation)
     const int c8 = (BK == 64 ? (lp ^ lrow) : ((lp - 2 * (lrow >> 2)) & 3)) * 8;
-    int apix[NA], ayx[NA];      // flat input pixel of tap (0,0) and packed (iy0 + 2048) << 16 | (ix0 + 2048)
-    int apix2[UP ? NA : 1];     // UP: the pixel of the low-res source that nearest-2x upsampling maps onto this one
+    // LDS-DMA addressing (lds_dma16): per piece ONE per-lane byte offset, computed here once -- the lane's source row at
+    // the CENTRE tap (always inside the image) plus its swizzled chunk -- and a 9-bit mask of the taps that stay inside the
+    // image.  Per K-step the tap displacement and the channel chunk are wave-uniform: the displacement is added to the
+    // offset of lanes whose tap is valid (the others re-read the centre row; their B fragments are zeroed below), the chunk
+    // sits in the scalar base.  UP: two sources, one offset each (low-res pixel / full-res pixel).
+    unsigned actr[NA], actr2[UP ? NA : 1];
+    int avm[NA];
 #pragma unroll
     for (int k = 0; k < NA; ++k) {
         const int m = P0 + (wv + 8 * k) * RPP + lrow;
-        if (UP) apix2[k] = 0;
+        actr[k] = (unsigned)(c8 * 2);
+        avm[k] = 0;
+        if (UP) actr2[k] = (unsigned)(c8 * 2);
         if (wv + 8 * k < APIECES && m < a.M) {
             const int b = m / HoWo, rem = m - b * HoWo, oy = rem / a.Wo, ox = rem - oy * a.Wo;
             const int iy0 = oy * a.stride - PAD, ix0 = ox * a.stride - PAD;
-            apix[k] = (b * a.H + iy0) * a.W + ix0;
-            ayx[k] = ((iy0 + 2048) << 16) | (ix0 + 2048);
-            if (UP) apix2[k] = (b * (a.H >> 1) + (oy >> 1)) * (a.W >> 1) + (ox >> 1);
-        } else {
-            apix[k] = 0;
-            ayx[k] = 0;                                            // iy0 = ix0 = -2048: never valid
+            const unsigned pix = (unsigned)((b * a.H + iy0 + PAD) * a.W + ix0 + PAD);
+            actr[k] = pix * (unsigned)((UP ? a.ldi2 : a.ldi) * 2) + (unsigned)(c8 * 2);
+            if (UP) actr2[k] = (unsigned)((b * (a.H >> 1) + (oy >> 1)) * (a.W >> 1) + (ox >> 1)) * (unsigned)(a.ldi * 2) + (unsigned)(c8 * 2);
+            int msk = KS == 1 ? 1 : 0;
+            if (KS == 3) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+                    if ((unsigned)(iy0 + t / 3) < (unsigned)a.H && (unsigned)(ix0 + t % 3) < (unsigned)a.W) msk |= 1 << t;
+            }
+            avm[k] = msk;
         }
     }
-    int woff[NW];
+    unsigned woff[NW];
 #pragma unroll
-    for (int k = 0; k < NW; ++k) woff[k] = min(n0 + (wv + 8 * k) * RPP + lrow, a.CoutPad - 1) * wrow + c8;
+    for (int k = 0; k < NW; ++k) woff[k] = (unsigned)(min(n0 + (wv + 8 * k) * RPP + lrow, a.CoutPad - 1) * wrow + c8) * 2u;
     const int my_pieces = max(0, (APIECES - wv + 7) / 8) + max(0, (WPIECES - wv + 7) / 8);
-
-    auto issue = [&](int s) {
-        const int tap = s / cpt, cc = s - tap * cpt;
-        const int dy = KS == 1 ? 0 : tap / 3, dx = KS == 1 ? 0 : tap - dy * 3;
-        __half *slot = ring + (size_t)(s % NSLOT) * SLOTH;
-#pragma unroll
-        for (int k = 0; k < NA; ++k) {
-            if (wv + 8 * k < APIECES) {
-                const int iy = (ayx[k] >> 16) - 2048 + dy, ix = (ayx[k] & 0xffff) - 2048 + dx;
-                const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-                const int q = ok ? apix[k] + dy * a.W + dx : 0;
-                const __half *src = a.in + (size_t)q * a.ldi + cc * BK + c8;
-                if (UP) {   // torch.cat([upsample2x(low), skip], channel): each 64-channel chunk comes from one of the two
-                    const int ch = cc * BK;
-                    src = ch < a.c_split ? a.in + (size_t)apix2[k] * a.ldi + ch + c8
-                                         : a.in2 + (size_t)q * a.ldi2 + (ch - a.c_split) + c8;
-                }
-                __builtin_amdgcn_global_load_lds((glb_vptr)src, (lds_vptr)(slot + (wv + 8 * k) * 512), 16, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < NW; ++k) {
-            if (wv + 8 * k < WPIECES) {
-                const __half *src = a.w + (size_t)(woff[k] + tap * a.Cin + cc * BK);
-                __builtin_amdgcn_global_load_lds((glb_vptr)src, (lds_vptr)(slot + BM * BK + (wv + 8 * k) * 512), 16, 0, 0);
-            }
-        }
-    };
+    const unsigned ring0 = lds_addr(ring);
+    // issue state of the next step (scalar registers; macros, not lambdas: see k_conv3_big)
+    int is_tap = 0, is_cc = 0, is_slot = 0;
+    int is_toff = KS == 3 ? -(a.W + 1) * a.ldi * 2 : 0;            // byte displacement of the tap from the centre row
+    const char *is_abase = (const char *)a.in, *is_wbase = (const char *)a.w;
+    bool is_low = UP;                                              // UP: this chunk comes from the low-res tensor
+    unsigned is_lds = ring0;
+#define GB_ISSUE()                                                                                                  \
+    do {                                                                                                            \
+        _Pragma("unroll") for (int k_ = 0; k_ < NA; ++k_) {                                                         \
+            if (wv + 8 * k_ < APIECES) {                                                                            \
+                unsigned v_ = actr[k_];                                                                             \
+                if (KS == 3 && ((avm[k_] >> is_tap) & 1)) v_ += (unsigned)is_toff;                                  \
+                if (UP && is_low) v_ = actr2[k_];                                                                   \
+                lds_dma16(v_, is_abase, is_lds + (unsigned)(wv + 8 * k_) * 1024u);                                  \
+            }                                                                                                       \
+        }                                                                                                           \
+        _Pragma("unroll") for (int k_ = 0; k_ < NW; ++k_) {                                                         \
+            if (wv + 8 * k_ < WPIECES) lds_dma16(woff[k_], is_wbase, is_lds + (unsigned)(BM * BK * 2) + (unsigned)(wv + 8 * k_) * 1024u); \
+        }                                                                                                           \
+        ++is_cc;                                                                                                    \
+        if (is_cc == cpt) { is_cc = 0; ++is_tap; }                                                                  \
+        ++is_slot;                                                                                                  \
+        if (is_slot == NSLOT) is_slot = 0;                                                                          \
+        is_cc = __builtin_amdgcn_readfirstlane(is_cc);                                                              \
+        is_tap = __builtin_amdgcn_readfirstlane(is_tap);                                                            \
+        is_slot = __builtin_amdgcn_readfirstlane(is_slot);                                                          \
+        if (KS == 3) {                                                                                              \
+            const int dy_ = is_tap / 3, dx_ = is_tap - dy_ * 3;                                                     \
+            is_toff = ((dy_ - 1) * a.W + (dx_ - 1)) * a.ldi * 2;                                                    \
+        }                                                                                                           \
+        if (UP) {                                                                                                   \
+            const int ch_ = is_cc * BK;                                                                             \
+            is_low = ch_ < a.c_split;                                                                               \
+            is_abase = is_low ? (const char *)a.in + ch_ * 2 : (const char *)a.in2 + (ch_ - a.c_split) * 2;         \
+        } else {                                                                                                    \
+            is_abase = (const char *)a.in + is_cc * (BK * 2);                                                       \
+        }                                                                                                           \
+        is_wbase = (const char *)a.w + (size_t)(is_tap * a.Cin + is_cc * BK) * 2;                                   \
+        is_lds = ring0 + (unsigned)is_slot * (unsigned)(SLOTH * 2);                                                 \
+    } while (0)
 
     // tap validity of this lane's pixels (bit = tap index); 1x1: every tap valid
     int vm[FM];
@@ -1440,7 +1514,7 @@ __global__ void __launch_bounds__(512)
 
 #pragma unroll
     for (int t = 0; t < NSLOT - 1; ++t)
-        if (t < nsteps) issue(t);
+        if (t < nsteps) GB_ISSUE();
     const int xr = lane & 7;                                       // BK 64: (row & 7) of every fragment row this lane reads
     for (int s = 0; s < nsteps; ++s) {
         wait_vm_n(NSLOT == 3 && s + 1 < nsteps ? my_pieces : 0);
@@ -1448,7 +1522,7 @@ __global__ void __launch_bounds__(512)
         const int sn = s + NSLOT - 1;
         const bool more = sn < nsteps;
         const bool early = NSLOT == 2 || wv < 4;
-        if (more && early) issue(sn);
+        if (more && early) GB_ISSUE();
         const int tap = s / cpt;
         const __half *ab = ring + (size_t)(s % NSLOT) * SLOTH;
         const __half *wb = ab + BM * BK;
@@ -1470,8 +1544,9 @@ __global__ void __launch_bounds__(512)
                 for (int j = 0; j < FM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[j], acc[i][j], 0, 0, 0);
             }
         }
-        if (more && !early) issue(sn);
+        if (more && !early) GB_ISSUE();
     }
+#undef GB_ISSUE
     __syncthreads();     // ring drained and no longer read: reuse it as the output staging tile
 
     constexpr int SROW = BN + 8;
@@ -1575,6 +1650,10 @@ hipError_t launch_gbig1(ConvArgs &a, hipStream_t s)
     static_assert(smem <= 160 * 1024, "LDS budget");
     if (hipError_t e = rva_func_smem((const void *)k_conv_gbig<BM, BN, WGM, WGN, NSLOT, KS, BK, UP, HEAD>, smem); e != hipSuccess) return e;
     a.n_tiles = rva_ceil_div(a.Cout, BN);
+    // LDS-DMA addresses are a 64-bit scalar base + a 32-bit per-lane byte offset
+    if ((size_t)a.H * a.W * (size_t)(a.M / (a.Ho * a.Wo) + 1) * (UP ? a.ldi2 : a.ldi) * 2 >= (1ull << 32) ||
+        (size_t)a.CoutPad * KS * KS * a.Cin * 2 >= (1ull << 32))
+        return hipErrorInvalidValue;
     k_conv_gbig<BM, BN, WGM, WGN, NSLOT, KS, BK, UP, HEAD><<<rva_ceil_div(a.M, BM) * a.n_tiles, 512, smem, s>>>(a);
     return hipGetLastError();
 }

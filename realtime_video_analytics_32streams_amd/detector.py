@@ -124,6 +124,7 @@ class HipYoloDetector(BaseDetector):
         # pointers to them, and an interleaved predict() with another batch size must not free what a graph replays on
         self._post_bufs: dict = {}
         self._in_bufs: dict = {}
+        self._in_border: dict = {}                        # batch size -> frame geometry whose letterbox border the buffer holds
         self._post: Optional[ops.PostBuffers] = None      # result buffers of the latest call
         self._in: Optional[torch.Tensor] = None           # input tensor of the latest call
         if config.warmup and self.net is not None:  # detector.py:588-593
@@ -140,11 +141,18 @@ class HipYoloDetector(BaseDetector):
             self._in = self._in_bufs[n] = torch.empty((n, 3, *self.input_hw), dtype=dt, device=self.device)
         f0 = frames[0]
         if isinstance(f0, ops.Nv12Surface):
-            return ops.preprocess_nv12(frames, self.input_hw, self.half, out=self._in, ctx=self.ctx)
+            # the border (pad value) of the input tensor is constant per geometry: the first launch into a buffer writes it,
+            # the following ticks of the same geometry write the content rows only
+            key = (f0.width, f0.height) if not any(f.mask is not None for f in frames) else None
+            steady = key is not None and self._in_border.get(n) == key
+            res = ops.preprocess_nv12(frames, self.input_hw, self.half, out=self._in, ctx=self.ctx, content_only=steady)
+            self._in_border[n] = key
+            return res
         dev = []
         for f in frames:  # host BGR ndarray (the reference's FramePacket.frame) or device tensor
             t = torch.from_numpy(np.ascontiguousarray(f)) if isinstance(f, np.ndarray) else f
             dev.append(t.to(self.device, non_blocking=True).contiguous())
+        self._in_border[n] = None
         return ops.preprocess_bgr(dev, self.input_hw, self.half, out=self._in, ctx=self.ctx)
 
     def invalidate_engine(self) -> None:

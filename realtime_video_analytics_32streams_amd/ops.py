@@ -59,8 +59,10 @@ class Nv12Surface:
 
 
 def preprocess_nv12(surfaces: Sequence[Nv12Surface], dst_hw=(640, 640), half: bool = True,
-                    out: Optional[torch.Tensor] = None, clip: bool = False, ctx: Optional[N.Context] = None):
-    """K1 over a tick of NV12 surfaces -> ``out[n,3,H,W]`` (+ letterbox meta unless ``clip``)."""
+                    out: Optional[torch.Tensor] = None, clip: bool = False, ctx: Optional[N.Context] = None,
+                    content_only: bool = False):
+    """K1 over a tick of NV12 surfaces -> ``out[n,3,H,W]`` (+ letterbox meta unless ``clip``).  ``content_only``: ``out``
+    already holds the letterbox border of this geometry (an earlier full call wrote it); write the content rows only."""
     ctx = ctx or context()
     n = len(surfaces)
     w, h = surfaces[0].width, surfaces[0].height
@@ -90,9 +92,9 @@ def preprocess_nv12(surfaces: Sequence[Nv12Surface], dst_hw=(640, 640), half: bo
                                                     N.RVA_F16 if half else N.RVA_F32, dst_hw[1], dst_hw[0], C.byref(meta),
                                                     _stream_ptr())
         else:
-            rc = L.rva_preprocess_nv12_batch(ctx.handle, yp, up, pp, len(chunk), w, h, optr,
-                                             N.RVA_F16 if half else N.RVA_F32, dst_hw[1], dst_hw[0], C.byref(meta),
-                                             _stream_ptr())
+            fn = L.rva_preprocess_nv12_content_batch if content_only else L.rva_preprocess_nv12_batch
+            rc = fn(ctx.handle, yp, up, pp, len(chunk), w, h, optr, N.RVA_F16 if half else N.RVA_F32, dst_hw[1], dst_hw[0],
+                    C.byref(meta), _stream_ptr())
         ctx.check(rc, "rva_preprocess_nv12_batch")
     return (out, None) if clip else (out, meta)
 

@@ -290,12 +290,13 @@ def test_config4_shape_8x4k_cnn_lstm_clips_through_the_pipeline():
         if any(r.detections_emitted.get(n, 0) for n in pipe.names):
             fired.append(t)
             assert all(r.detections_emitted[n] == 5 for n in pipe.names)           # top-5 of the raw output, every stream
-            first = first or r
+            if first is None:      # Track objects alias tracker state (as in the reference): copy what tick 31 looked like
+                first = {n: [copy.copy(t) for t in v] for n, v in r.tracks.items()}
     assert fired == [f for s, f in rec["fired"] if s == "a" and f < T]             # 31, 39
     # tick 31: 8 streams x 5 new tracks (5 distinct classes each), ids 1..40 in stream order
-    ids = [[t.track_id for t in first.tracks[n]] for n in pipe.names]
+    ids = [[t.track_id for t in first[n]] for n in pipe.names]
     assert ids == [list(range(5 * i + 1, 5 * i + 6)) for i in range(S)]
-    tr = first.tracks["uhd3"][0]
+    tr = first["uhd3"][0]
     assert tr.bbox_xyxy == (0.0, 0.0, 3840.0, 2160.0) and tr.sequence_start_frame == 0 and tr.sequence_end_frame == 30
     assert tr.action_label == f"act{tr.class_id}"
     # the clip of stream 3 at tick 31: frames 0, 2, ..., 30 (the ring of 2 synthetic frames alternates) -> CPU fp32 reference
@@ -304,6 +305,6 @@ def test_config4_shape_8x4k_cnn_lstm_clips_through_the_pipeline():
     with torch.inference_mode():
         want = net(torch.from_numpy(x)[None]).flatten().numpy()
     top = np.argsort(want, kind="stable")[-5:][::-1]
-    got = first.tracks["uhd3"]
+    got = first["uhd3"]
     assert [t.class_id for t in got] == top.tolist()
     assert np.allclose([t.confidence for t in got], want[top], atol=1e-3)
