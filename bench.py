@@ -28,7 +28,9 @@ import torch
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-K1_BYTES_PER_FRAME = 3_840_000          # 360 Y rows + 360 UV rows x 1920 B in, 3x640x640 fp16 out
+K1_BYTES_FULL = 3_840_000               # 360 Y rows + 360 UV rows x 1920 B in, 3x640x640 fp16 out (border included)
+K1_BYTES_PER_FRAME = 2_764_800          # SURVEY.md 8(d) alternate, what the steady-state kernel moves: the same input rows
+                                        # + the 360 content rows of the tensor (the constant border is written once per buffer)
 HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_PEAK_TFLOPS = 2500.0               # dense fp16
 
@@ -67,6 +69,21 @@ def parse():
 
 
 K1_SAMPLE_EVERY = 4      # ticks between dispatch-level timings of K1 inside the timed region
+
+
+def k1_bytes(w, h, content_only=True, dst=640):
+    """Algorithmic bytes of one frame through K1: the source rows the resize taps touch (Y + UV, whole
+    rows) + the tensor rows written (content rows only in steady state, the whole 3 x dst x dst tensor otherwise)."""
+    scale = min(dst / w, dst / h)
+    nw, nh = int(w * scale), int(h * scale)
+    if w % nw == 0 and h % nh == 0 and w // nw == h // nh:
+        r = w // nw
+        ys = {r * y + (r - 1) // 2 for y in range(nh)} if r % 2 else {r * y + r // 2 - 1 + k for y in range(nh) for k in (0, 1)}
+    else:
+        ys = set(range(h))                     # fractional geometry: two taps per output row, in practice every source row
+    rows_in = len(ys) + len({y >> 1 for y in ys})
+    out = 3 * (nh * nw if content_only else dst * dst) * 2
+    return rows_in * w + out
 
 
 def spawn_ranks(args) -> int:
@@ -243,11 +260,13 @@ def main():
     net_ms, post_ms, trk_ms = stage.mean(0)
     frames = world * S * K
     fps = frames / elapsed
-    k1_gbs = K1_BYTES_PER_FRAME * S / (k1_ms * 1e-3) / 1e9
+    k1_frame_bytes = k1_bytes(args.width, args.height)
+    assert (args.width, args.height) != (1920, 1080) or k1_frame_bytes == K1_BYTES_PER_FRAME
+    k1_gbs = k1_frame_bytes * S / (k1_ms * 1e-3) / 1e9
     # HBM traffic of the K1 launch from rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see the file): a
     # committed measurement of exactly this launch shape, not something bench.py can collect while timing
     k1_traffic = None
-    pmc = ROOT / "profiles" / "r01_k1_pmc.json"
+    pmc = ROOT / "profiles" / "r02_k1_pmc.json"
     if pmc.exists() and S == 32 and (args.width, args.height) == (1920, 1080):
         k1_traffic = json.loads(pmc.read_text())["traffic_bytes_per_launch"]
     net_tflops = 2 * macs * S / (net_ms * 1e-3) / 1e12
@@ -277,11 +296,12 @@ def main():
                       "k2k3_postprocess": round(float(post_ms), 4), "k4_tracker": round(float(trk_ms), 4)},
         "detections_per_frame": round(dets_emitted / S, 2), "tracks_per_stream": round(n_tracks / (K * S), 2),
         "detector_tflops": round(net_tflops, 2), "detector_frac_of_mfma_peak": round(net_tflops / MFMA_PEAK_TFLOPS, 4),
-        "roofline": {"kernel": "k1_ratio<3,half> (NV12 1080p -> fp16 3x640x640, one launch per tick)", "bound": "hbm",
+        "roofline": {"kernel": "k1_ratio_content<3,half,2> (NV12 1080p -> content rows of fp16 3x640x640, one launch per tick; the "
+                               "constant letterbox border was written by the first launch into the buffer)", "bound": "hbm",
                      "achieved": round(k1_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(k1_gbs / HBM_PEAK_GBS, 4), "traffic": k1_traffic,
-                     "traffic_source": "profiles/r01_k1_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" if k1_traffic else None,
-                     "algorithmic_bytes_per_launch": K1_BYTES_PER_FRAME * S, "avg_launch_us": round(float(k1_ms) * 1e3, 2),
+                     "traffic_source": "profiles/r02_k1_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" if k1_traffic else None,
+                     "algorithmic_bytes_per_launch": k1_frame_bytes * S, "avg_launch_us": round(float(k1_ms) * 1e3, 2),
                      "avg_launch_us_between_event_records": round(float(k1_bracket_ms) * 1e3, 2),
                      "timing": f"HIP start/stop events of the K1 dispatch itself (hipExtLaunchKernelGGL), every {K1_SAMPLE_EVERY}th timed tick "
                                "(the event packets cost ~10 us of queue time per use)"},
@@ -308,24 +328,40 @@ def extras(args, out, sources, rctx, dev, dcfg, tcfg):
     S = len(sources)
     surf = [src._ring[0] for src in sources]
     outb = torch.empty((S, 3, 640, 640), dtype=torch.float16, device=dev)
-    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(8)]
-    for pair in evs:
-        for e in pair:
-            e.record()
-    scratch = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
-    torch.cuda.synchronize()
-    for a, b in evs:
-        scratch.fill_(1)                                          # 512 MiB of writes: evicts the 256 MiB Infinity Cache
-        N.lib().rva_profile_next_preprocess(rctx.handle, a.cuda_event, b.cuda_event)
-        ops.preprocess_nv12(surf, (640, 640), half=True, out=outb, ctx=rctx)
-    torch.cuda.synchronize()
-    cold_ms = float(np.median([a.elapsed_time(b) for a, b in evs]))
+    scratch = torch.empty(512 << 20, dtype=torch.uint8, device=dev).fill_(1)
+    ops.preprocess_nv12(surf, (640, 640), half=True, out=outb, ctx=rctx)      # full launch: writes the border of `outb`
+
+    def k1_us(content, sweep, reps=8):
+        ts = []
+        for _ in range(reps):
+            if sweep == "read":
+                scratch.view(torch.int64).sum()                   # 512 MiB of reads: evicts the 256 MiB Infinity Cache, lines stay clean
+            elif sweep == "write":
+                scratch.fill_(1)                                  # ... or leaves it full of dirty lines K1 has to push out
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); b.record()
+            torch.cuda.synchronize()
+            N.lib().rva_profile_next_preprocess(rctx.handle, a.cuda_event, b.cuda_event)
+            ops.preprocess_nv12(surf, (640, 640), half=True, out=outb, ctx=rctx, content_only=content)
+            torch.cuda.synchronize()
+            ts.append(a.elapsed_time(b))
+        return float(np.median(ts))
     roof = out["roofline"]
-    if cold_ms > 1e-3:                                            # events were written by the dispatch (integer-ratio K1 path)
+    cold_ms = k1_us(True, "read")
+    if cold_ms > 1e-3 and (args.width, args.height) == (1920, 1080):      # events were written by the dispatch (integer-ratio K1 path)
         gbs = roof["algorithmic_bytes_per_launch"] / (cold_ms * 1e-3) / 1e9
         roof["cold_launch_us"] = round(cold_ms * 1e3, 2)
         roof["cold_achieved"] = round(gbs, 1)
         roof["cold_frac"] = round(gbs / HBM_PEAK_GBS, 4)
+        roof["cold_state"] = "after a 512 MiB read sweep (Infinity Cache evicted, clean)"
+        dirty_ms = k1_us(True, "write")
+        roof["cold_after_write_sweep_us"] = round(dirty_ms * 1e3, 2)
+        full = {"kernel": "k1_ratio<3,half> (border included: first launch into a buffer)", "algorithmic_bytes_per_launch": K1_BYTES_FULL * S}
+        for key, sweep in (("warm", None), ("cold", "read")):
+            ms = k1_us(False, sweep)
+            full[f"{key}_launch_us"] = round(ms * 1e3, 2)
+            full[f"{key}_frac"] = round(K1_BYTES_FULL * S / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        roof["full_tensor_kernel"] = full
     # device copy rate: 1 GiB -> 1 GiB, bytes moved = read + written
     n = 1 << 30
     src_b = torch.empty(n, dtype=torch.uint8, device=dev).fill_(3)

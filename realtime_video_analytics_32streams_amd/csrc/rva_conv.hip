@@ -1067,7 +1067,7 @@ struct BigArgs {
     const __half *w; const float *bias;
     __half *out; int ldo;
     const __half *res; int ldr;
-    int H, W, Cin, Cout, CoutPad, act, n_tiles, M;
+    int H, W, Cin, Cout, CoutPad, act, n_tiles, M, m_tiles;
 };
 
 typedef __attribute__((address_space(3))) void *lds_vptr;
@@ -1125,7 +1125,11 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NSLOT 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wv % WGM, wn = wv / WGM;
-    const int n_tile = blockIdx.x % a.n_tiles, m_tile = blockIdx.x / a.n_tiles;
+    // XCD-aware tile order: workgroups id and id + 8 land on the same XCD (round-robin dispatch; speed only, never
+    // correctness), so the n-tiles of one m-tile -- which stage the same activation rows -- are given ids 8 apart: they
+    // share that XCD's L2 instead of pulling the rows across the fabric once per n-tile.  Identity when n_tiles == 1.
+    const int n_tile = (blockIdx.x >> 3) % a.n_tiles, m_tile = ((blockIdx.x >> 3) / a.n_tiles) * 8 + (blockIdx.x & 7);
+    if (m_tile >= a.m_tiles) return;                      // grid is padded to a multiple of 8 m-tiles
     const int P0 = m_tile * BM, n0 = n_tile * BN;
     const int HW = a.H * a.W;
     const int cpt = a.Cin >> 5;
@@ -1365,7 +1369,8 @@ hipError_t launch_big(BigArgs &a, hipStream_t s)
     if ((size_t)a.M * a.ldi * 2 >= (1ull << 32) || (size_t)a.CoutPad * 9 * a.Cin * 2 >= (1ull << 32)) return hipErrorInvalidValue;
     if (hipError_t e = rva_func_smem((const void *)k_conv3_big<BM, BN, WGM, WGN, NSLOT>, smem); e != hipSuccess) return e;
     a.n_tiles = rva_ceil_div(a.Cout, BN);
-    k_conv3_big<BM, BN, WGM, WGN, NSLOT><<<rva_ceil_div(a.M, BM) * a.n_tiles, 512, smem, s>>>(a);
+    a.m_tiles = rva_ceil_div(a.M, BM);
+    k_conv3_big<BM, BN, WGM, WGN, NSLOT><<<rva_ceil_div(a.m_tiles, 8) * 8 * a.n_tiles, 512, smem, s>>>(a);
     return hipGetLastError();
 }
 
@@ -1398,7 +1403,9 @@ __global__ void __launch_bounds__(512)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wv % WGM, wn = wv / WGM;
-    const int n_tile = blockIdx.x % a.n_tiles, m_tile = blockIdx.x / a.n_tiles;
+    // XCD-aware tile order (see k_conv3_big): the n-tiles of one m-tile get workgroup ids 8 apart
+    const int n_tile = (blockIdx.x >> 3) % a.n_tiles, m_tile = ((blockIdx.x >> 3) / a.n_tiles) * 8 + (blockIdx.x & 7);
+    if (m_tile >= a.m_tiles) return;
     const int P0 = m_tile * BM, n0 = n_tile * BN;
     const int HoWo = a.Ho * a.Wo;
     const int cpt = a.Cin / BK;
@@ -1654,7 +1661,8 @@ hipError_t launch_gbig1(ConvArgs &a, hipStream_t s)
     if ((size_t)a.H * a.W * (size_t)(a.M / (a.Ho * a.Wo) + 1) * (UP ? a.ldi2 : a.ldi) * 2 >= (1ull << 32) ||
         (size_t)a.CoutPad * KS * KS * a.Cin * 2 >= (1ull << 32))
         return hipErrorInvalidValue;
-    k_conv_gbig<BM, BN, WGM, WGN, NSLOT, KS, BK, UP, HEAD><<<rva_ceil_div(a.M, BM) * a.n_tiles, 512, smem, s>>>(a);
+    a.m_tiles = rva_ceil_div(a.M, BM);
+    k_conv_gbig<BM, BN, WGM, WGN, NSLOT, KS, BK, UP, HEAD><<<rva_ceil_div(a.m_tiles, 8) * 8 * a.n_tiles, 512, smem, s>>>(a);
     return hipGetLastError();
 }
 
