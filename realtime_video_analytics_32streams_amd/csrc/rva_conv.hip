@@ -1118,7 +1118,6 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NSLOT 
     constexpr int PIECES = APIECES + WPIECES;
     constexpr int SLOTH = PIECES * 512;                   // halfs per ring slot
     constexpr int NP = (PIECES + 7) / 8;                  // pieces per wave per step (upper bound)
-    static_assert(NSLOT == 3 || NP <= 3 * FN, "the two-slot form issues one piece per (dx, i) MFMA group");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __half *ring = (__half *)smem;                        // [NSLOT][PIECES][16][32]
 
@@ -1252,7 +1251,10 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NSLOT 
         // their DMA burst before the MFMAs and the upper four after them -- while one wave of a SIMD is busy issuing
         // (~750 cycles), the other one keeps the matrix core fed
         const bool early = wv < 4;
-        if (NSLOT == 3 && more && early) BIG_ISSUE();
+        // two slots: the whole burst goes out right after the barrier too (every wave has left the slot it overwrites); with
+        // the pieces interleaved between the MFMA groups the last one was issued two thirds into the step and its ~900-cycle
+        // flight showed up as ~430 cycles of vmcnt wait per step
+        if (more && (NSLOT == 2 || early)) BIG_ISSUE();
         STAMP(4);
         const int dy = s / cpt;
         const __half *ab = ring + (size_t)(s % NSLOT) * SLOTH;
@@ -1296,16 +1298,10 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NSLOT 
                     const h8 a1 = *reinterpret_cast<const h8 *>(wb + swz32(dx * BN + wn * TN + i * 16 + (lane & 15), ch));
 #pragma unroll
                     for (int j = 0; j < FM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bf[0][j], acc[i][j], 0, 0, 0);
-                    // two slots (2-3 blocks per CU): one LDS-DMA piece of the next step per MFMA group
-                    if (dx * FN + i < NP) {
-                        if (more) BIG_ISSUE_PIECE(dx * FN + i);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
                 }
             }
         }
         if (NSLOT == 3 && more && !early) BIG_ISSUE();
-        if (NSLOT == 2 && more) BIG_ISSUE_ADVANCE();
         STAMP(5);
     }
     __syncthreads();     // all waves done with the ring: reuse it as the output staging tile
@@ -1371,6 +1367,210 @@ hipError_t launch_big(BigArgs &a, hipStream_t s)
     a.n_tiles = rva_ceil_div(a.Cout, BN);
     a.m_tiles = rva_ceil_div(a.M, BM);
     k_conv3_big<BM, BN, WGM, WGN, NSLOT><<<rva_ceil_div(a.m_tiles, 8) * 8 * a.n_tiles, 512, smem, s>>>(a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 3x3 stride-1 convolution, "long run" LDS-DMA variant.
+//
+// k_conv3_big stages the activation run of a tile once per (vertical tap, channel chunk): every row travels L2 -> LDS three
+// times.  s_memtime stamps after the address rewrite (profiles/r02_conv_stamps.txt) show what is left of a K-step: the
+// 24-48 MFMAs of the wave (MFMA-bound while they run, ~62 % of the step) and 0.6-0.7 k cycles of load wait + barrier --
+// the per-CU vector-memory path moves 29-41 KB per step and block and is the co-limiter.  Here a 32-channel chunk's run is
+// staged ONCE for all three vertical taps: rows [P0 - W - 1, P0 + BM + W + 1) of the flat pixel raster (BM + 2W + 2 rows
+// instead of 3 x (BM + 2)), double buffered across chunks; only the weights of a (chunk, dy) step stream per step.
+// 128 -> 128 at 40x40 with a 256 x 64 tile: 233 instead of 345 KB per tile (-32 %), and 68 KB of LDS, so two blocks per
+// CU overlap each other's epilogues.  K order: chunk-major, then dy, then dx (fp32 accumulation, one rounding at the end
+// like every other variant).  Tap validity, swizzle, epilogue as in k_conv3_big.  Needs Cin % 32 == 0 and W <= 160.
+struct RunArgs {
+    const __half *in; int ldi;
+    const __half *w; const float *bias;
+    __half *out; int ldo;
+    const __half *res; int ldr;
+    int H, W, Cin, Cout, CoutPad, act, n_tiles, M, m_tiles, apieces;
+};
+
+template <int BM, int BN, int WGM, int WGN>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BN <= 64 ? 4 : 2))) k_conv3_run(RunArgs a)
+{
+    static_assert(WGM * WGN == 8, "eight waves");
+    constexpr int TM = BM / WGM, TN = BN / WGN, FM = TM / 16, FN = TN / 16;
+    constexpr int WPIECES = 3 * BN / 16;                  // weights [3 dx][BN] rows of one (chunk, dy) step
+    constexpr int NPW = (WPIECES + 7) / 8;
+    constexpr int MAXA = 5;                               // activation pieces per wave: ceil((BM + 2*160 + 2) / 16 / 8) for BM <= 256
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv % WGM, wn = wv / WGM;
+    const int n_tile = (blockIdx.x >> 3) % a.n_tiles, m_tile = ((blockIdx.x >> 3) / a.n_tiles) * 8 + (blockIdx.x & 7);   // XCD-aware, see k_conv3_big
+    if (m_tile >= a.m_tiles) return;
+    const int P0 = m_tile * BM, n0 = n_tile * BN;
+    const int HW = a.H * a.W;
+    const int cpt = a.Cin >> 5;
+    const int nsteps = 3 * cpt;
+    const int wrow = 9 * a.Cin;
+    const int apieces = a.apieces;                        // ceil((BM + 2W + 2) / 16)
+    __half *act0 = (__half *)smem;                        // [2][apieces][16][32]
+    __half *wt0 = act0 + (size_t)2 * apieces * 512;       // [2][WPIECES][16][32]
+    const unsigned lds_act = lds_addr(act0), lds_w = lds_addr(wt0);
+
+    const int lrow = lane >> 2, lp = lane & 3;
+    unsigned aoff[MAXA], woff[NPW];
+#pragma unroll
+    for (int k = 0; k < MAXA; ++k) {
+        const int r = (wv + 8 * k) * 16 + lrow;           // row of the run
+        const int q = min(max(P0 - a.W - 1 + r, 0), a.M - 1);
+        aoff[k] = (unsigned)q * (unsigned)(a.ldi * 2) + (unsigned)(((lp - 2 * (r >> 2)) & 3) * 16);
+    }
+#pragma unroll
+    for (int k = 0; k < NPW; ++k) {
+        const int rw = (wv + 8 * k) * 16 + lrow;
+        const int dx = rw / BN, co = min(n0 + rw - dx * BN, a.CoutPad - 1);
+        woff[k] = (unsigned)(co * wrow + min(dx, 2) * a.Cin) * 2u + (unsigned)(((lp - 2 * (rw >> 2)) & 3) * 16);
+    }
+    // 9-bit tap validity per pixel fragment
+    int vm[FM];
+#pragma unroll
+    for (int j = 0; j < FM; ++j) {
+        const int p = P0 + wm * TM + 16 * j + (lane & 15);
+        int m = 0;
+        if (p < a.M) {
+            const int rem = p % HW, oy = rem / a.W, ox = rem - oy * a.W;
+            const int hv = (ox >= 1 ? 1 : 0) | 2 | (ox <= a.W - 2 ? 4 : 0);
+            m = (oy >= 1 ? hv : 0) | (hv << 3) | (oy <= a.H - 2 ? hv << 6 : 0);
+        }
+        vm[j] = m;
+    }
+    f4 acc[FN][FM];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+    const h8 hz = {0, 0, 0, 0, 0, 0, 0, 0};
+    float4 bvs[FN];                                       // before the first DMA (see k_conv3_big)
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+        bvs[i] = *reinterpret_cast<const float4 *>(a.bias + min(n0 + wn * TN + 16 * i + (lane >> 4) * 4, a.CoutPad - 4));
+
+    // prologue: the whole run of chunk 0 and the weights of step 0
+#pragma unroll
+    for (int k = 0; k < MAXA; ++k)
+        if (wv + 8 * k < apieces) lds_dma16(aoff[k], a.in, lds_act + (unsigned)(wv + 8 * k) * 1024u);
+#pragma unroll
+    for (int k = 0; k < NPW; ++k)
+        if (wv + 8 * k < WPIECES) lds_dma16(woff[k], a.w, lds_w + (unsigned)(wv + 8 * k) * 1024u);
+
+    int cc = 0, dy = 0;
+    for (int s = 0; s < nsteps; ++s) {
+        wait_vm<0>();                                     // everything this wave issued a step ago has landed ...
+        __builtin_amdgcn_s_barrier();                     // ... and everybody's has; nobody still reads what the next burst overwrites
+        // next step's weights, and this step's third of the NEXT chunk's run
+        int ncc = cc, ndy = dy + 1;
+        if (ndy == 3) { ndy = 0; ++ncc; }
+        ncc = __builtin_amdgcn_readfirstlane(ncc);
+        ndy = __builtin_amdgcn_readfirstlane(ndy);
+        // waves w and w + 4 share a SIMD: the lower four issue their burst before the MFMAs, the upper four after the first
+        // horizontal tap -- while one of the pair is stalled in the vector-memory issue, the other keeps the matrix core fed
+        // (both bursts still have most of a step to land before the next top-of-step wait)
+#define RUN_ISSUE()                                                                                              \
+        do {                                                                                                     \
+            if (s + 1 < nsteps) {                                                                                \
+                const char *wb_ = (const char *)a.w + (size_t)(ndy * 3 * a.Cin + ncc * 32) * 2;                  \
+                const unsigned l_ = lds_w + (unsigned)((s + 1) & 1) * (unsigned)(WPIECES * 1024);                \
+                _Pragma("unroll") for (int k = 0; k < NPW; ++k)                                                  \
+                    if (wv + 8 * k < WPIECES) lds_dma16(woff[k], wb_, l_ + (unsigned)(wv + 8 * k) * 1024u);      \
+            }                                                                                                    \
+            if (cc + 1 < cpt) {                                                                                  \
+                const char *ab_ = (const char *)a.in + (cc + 1) * 64;                                            \
+                const unsigned l_ = lds_act + (unsigned)((cc + 1) & 1) * (unsigned)(apieces * 1024);             \
+                _Pragma("unroll") for (int k = 0; k < MAXA; ++k)                                                 \
+                    if (k % 3 == dy && wv + 8 * k < apieces) lds_dma16(aoff[k], ab_, l_ + (unsigned)(wv + 8 * k) * 1024u); \
+            }                                                                                                    \
+        } while (0)
+        const bool early = wv < 4;
+        if (early) RUN_ISSUE();
+        const __half *ab = act0 + (size_t)(cc & 1) * apieces * 512;
+        const __half *wb = wt0 + (size_t)(s & 1) * WPIECES * 512;
+        const int arow = wm * TM + (lane & 15) + dy * a.W, ch = lane >> 4;
+        const int vsh = dy * 3;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            h8 bf[FM];
+#pragma unroll
+            for (int j = 0; j < FM; ++j) {
+                bf[j] = *reinterpret_cast<const h8 *>(ab + swz32(arow + j * 16 + dx, ch));
+                if (!((vm[j] >> (vsh + dx)) & 1)) bf[j] = hz;
+            }
+#pragma unroll
+            for (int i = 0; i < FN; ++i) {
+                const h8 a1 = *reinterpret_cast<const h8 *>(wb + swz32(dx * BN + wn * TN + i * 16 + (lane & 15), ch));
+#pragma unroll
+                for (int j = 0; j < FM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bf[j], acc[i][j], 0, 0, 0);
+            }
+            if (dx == 0 && !early) RUN_ISSUE();
+        }
+#undef RUN_ISSUE
+        cc = ncc; dy = ndy;
+    }
+    __syncthreads();     // all waves done with the buffers: reuse them as the output staging tile
+
+    constexpr int SROW = BN + 8;
+    __half *stage = (__half *)smem;                       // [BM][SROW]
+#pragma unroll
+    for (int i = 0; i < FN; ++i) {
+        const int co = wn * TN + 16 * i + (lane >> 4) * 4;
+        const float4 bv = bvs[i];
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+            float v0 = acc[i][j][0] + bv.x, v1 = acc[i][j][1] + bv.y, v2 = acc[i][j][2] + bv.z, v3 = acc[i][j][3] + bv.w;
+            if (a.act) { v0 = silu_f(v0); v1 = silu_f(v1); v2 = silu_f(v2); v3 = silu_f(v3); }
+            const int px = wm * TM + 16 * j + (lane & 15);
+            __half2 lo = __floats2half2_rn(v0, v1), hi = __floats2half2_rn(v2, v3);
+            uint2 pk;
+            pk.x = *reinterpret_cast<uint32_t *>(&lo);
+            pk.y = *reinterpret_cast<uint32_t *>(&hi);
+            *reinterpret_cast<uint2 *>(stage + (size_t)px * SROW + co) = pk;
+        }
+    }
+    __syncthreads();
+    constexpr int CPR = BN / 8;
+#pragma unroll 4
+    for (int q = tid; q < BM * CPR; q += 512) {
+        const int row = q / CPR, pc = q - row * CPR;
+        const int co = n0 + pc * 8;
+        const int m = P0 + row;
+        if (m < a.M && co < a.Cout) {
+            uint4 v = *reinterpret_cast<const uint4 *>(stage + (size_t)row * SROW + pc * 8);
+            if (a.res) {
+                const uint4 r = *reinterpret_cast<const uint4 *>(a.res + (size_t)m * a.ldr + co);
+                __half2 *vh = reinterpret_cast<__half2 *>(&v);
+                const __half2 *rh = reinterpret_cast<const __half2 *>(&r);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float2 x = __half22float2(vh[u]), y = __half22float2(rh[u]);
+                    vh[u] = __floats2half2_rn(x.x + y.x, x.y + y.y);
+                }
+            }
+            *reinterpret_cast<uint4 *>(a.out + (size_t)m * a.ldo + co) = v;
+        }
+    }
+}
+
+template <int BM, int BN, int WGM, int WGN>
+hipError_t launch_run(RunArgs &a, hipStream_t s)
+{
+    if (a.Cin % 32 || a.CoutPad % 4 || a.W > 160) return hipErrorInvalidValue;
+    if ((size_t)a.M * a.ldi * 2 >= (1ull << 32) || (size_t)a.CoutPad * 9 * a.Cin * 2 >= (1ull << 32)) return hipErrorInvalidValue;
+    a.apieces = rva_ceil_div(BM + 2 * a.W + 2, 16);
+    if (a.apieces > 8 * 5) return hipErrorInvalidValue;   // MAXA pieces per wave
+    const size_t ring = (size_t)(2 * a.apieces + 2 * (3 * BN / 16)) * 1024;
+    const size_t st = (size_t)BM * (BN + 8) * 2;
+    const size_t smem = ring > st ? ring : st;
+    if (smem > 160 * 1024) return hipErrorInvalidValue;
+    if (hipError_t e = rva_func_smem((const void *)k_conv3_run<BM, BN, WGM, WGN>, 160 * 1024); e != hipSuccess) return e;
+    a.n_tiles = rva_ceil_div(a.Cout, BN);
+    a.m_tiles = rva_ceil_div(a.M, BM);
+    k_conv3_run<BM, BN, WGM, WGN><<<rva_ceil_div(a.m_tiles, 8) * 8 * a.n_tiles, 512, smem, s>>>(a);
     return hipGetLastError();
 }
 
@@ -1894,7 +2094,7 @@ hipError_t launch_patch(S2Args &g, int num_cus, hipStream_t s)
 
 }  // namespace
 
-#define RVA_CONV_VARIANTS 51
+#define RVA_CONV_VARIANTS 60
 
 extern "C" {
 #ifdef RVA_ROW_STAMPS
@@ -1969,6 +2169,29 @@ int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *wei
                                                  stride, act, pick, stream_);
             if (rc == RVA_OK) return rc;
         }
+    }
+    if (variant >= 52) {
+        // "long run" LDS-DMA kernels (3x3 stride 1, Cin % 32 == 0): a chunk's activation run staged once for all three dy
+        hipError_t ev = hipErrorInvalidValue;
+        if (ksize == 3 && stride == 1) {
+            RunArgs g{};
+            g.in = a.in; g.ldi = ldi; g.w = a.w; g.bias = bias; g.out = a.out; g.ldo = ldo; g.res = a.res; g.ldr = ldr;
+            g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.CoutPad = rva_ceil_div(Cout, 64) * 64; g.act = act; g.M = a.M;
+            switch (variant) {
+            case 52: ev = launch_run<256, 64, 4, 2>(g, s); break;
+            case 53: ev = launch_run<128, 64, 2, 4>(g, s); break;
+            case 54: ev = launch_run<384, 64, 8, 1>(g, s); break;
+            case 55: ev = launch_run<192, 128, 4, 2>(g, s); break;
+            case 56: ev = launch_run<256, 128, 4, 2>(g, s); break;
+            case 57: ev = launch_run<128, 128, 2, 4>(g, s); break;
+            case 58: ev = launch_run<224, 128, 2, 4>(g, s); break;    // tile heights that fit whole rounds of the 256 CUs better
+            case 59: ev = launch_run<160, 128, 2, 4>(g, s); break;
+            default: ev = launch_run<320, 64, 4, 2>(g, s); break;
+            }
+        }
+        if (ev == hipSuccess) return RVA_OK;
+        (void)hipGetLastError();
+        return rva_fail(ctx, ev == hipErrorInvalidValue ? RVA_ERR_ARG : RVA_ERR_HIP, "conv variant %d not applicable here", variant);
     }
     if (variant >= 43) {
         // patch kernels (weights resident in LDS): Cin = 32: 43 = 3x3 stride 2, Cout <= 64 (the first downsampling

@@ -62,8 +62,15 @@ class FusedYoloV8:
         self.L = N.lib()
         self._keep: List[torch.Tensor] = []
         self._steps: List[Callable[[C.c_void_p], None]] = []
+        self._lane_of: List[int] = []       # per step: 0 = main stream, k > 0 = side stream k (detect-head branches)
+        self._lane = 0
+        self._forks: Dict[int, int] = {}    # side lane -> index of the first step that runs on it (fork point)
         self._tunable = []
         self._build(net)
+        self._lane_of += [self._lane] * (len(self._steps) - len(self._lane_of))
+        self._side = {}                     # lane -> torch.cuda.Stream, created on first use
+        import os
+        self.concurrent_heads = os.environ.get("RVA_SERIAL_HEADS") != "1"      # A/B switch for measurements
         if autotune:
             self.autotune()
 
@@ -204,6 +211,14 @@ class FusedYoloV8:
             ctx.check(L.rva_upsample2x_nhwc_f16(ctx.handle, src.ptr, src.ld, dst.ptr, dst.ld, B, h, w, src.ch, stream), "upsample")
         self._steps.append(run)
 
+    def _set_lane(self, lane: int) -> None:
+        """Steps appended from now on run on side stream ``lane`` (0 = main).  A side lane forks off the main stream at the
+        point of this call (everything appended before it on the main lane is its dependency) and joins at the end."""
+        self._lane_of += [self._lane] * (len(self._steps) - len(self._lane_of))
+        self._lane = lane
+        if lane and lane not in self._forks:
+            self._forks[lane] = len(self._steps)
+
     # -- the graph ------------------------------------------------------------------------------------
     def _build(self, net: YoloV8):
         B, H, W = self.B, self.H, self.W
@@ -259,9 +274,11 @@ class FusedYoloV8:
             self._c2f(net.h12, cat12, n4, h4, w4)
             self._upsample(n4, cat15.sub(0, c4), h4, w4)
             self._c2f(net.h15, cat15, n3, h3, w3)
+        fork_n3 = len(self._steps)                    # n3 is complete here: the stride-8 detect branch may start
         self._conv(net.h16, n3, cat18.sub(0, c3), h3, w3)
         m4 = _View(self._buf(B * h4 * w4, c4), 0, c4)
         self._c2f(net.h18, cat18, m4, h4, w4)
+        fork_m4 = len(self._steps)                    # m4 is complete: the stride-16 detect branch may start
         self._conv(net.h19, m4, cat21.sub(0, c4), h4, w4)
         m5 = _View(self._buf(B * h5 * w5, c5), 0, c5)
         self._c2f(net.h21, cat21, m5, h5, w5)
@@ -276,6 +293,15 @@ class FusedYoloV8:
         fuse_head = all(net.detect.box[l][2].in_channels % 64 == 0 and net.detect.cls[l][2].in_channels % 64 == 0 and
                         net.detect.box[l][2].out_channels == 64 and net.detect.cls[l][2].out_channels == self.nc for l in range(3))
         for lvl, (feat, hh, ww, stride) in enumerate(((n3, h3, w3, 8.0), (m4, h4, w4, 16.0), (m5, h5, w5, 32.0))):
+            # The three detect branches only depend on their own feature map and write disjoint anchor ranges of the
+            # result: the stride-8 branch (the big one) runs on a side stream beside the rest of the neck -- h16 ... h21
+            # are 40x40 / 20x20 layers that leave most CUs idle -- and the stride-16 branch beside h19 / h21; they join
+            # the main stream at the end of the plan.  Only when the decode is fused into the branches (no k_head3).
+            if fuse_head and lvl < 2:
+                self._set_lane(lvl + 1)
+                self._forks[lvl + 1] = fork_n3 if lvl == 0 else fork_m4
+            else:
+                self._set_lane(0)
             box, cls = net.detect.box[lvl], net.detect.cls[lvl]
             m = B * hh * ww
             cb = box[0].conv.out_channels
@@ -297,6 +323,7 @@ class FusedYoloV8:
                 self._conv(cls[1], k1, k2, hh, ww); self._conv(cls[2], k2, ko, hh, ww)
             levels.append((bo, ko, hh, ww, stride))
             a0 += hh * ww
+        self._set_lane(0)
         if fuse_head:
             return
         # DFL + dist2bbox + sigmoid of the three levels in one launch
@@ -347,9 +374,35 @@ class FusedYoloV8:
         """``x``: fp16 planar ``[B,3,H,W]`` contiguous (what K1 writes).  Returns ``[B, 4+nc, A]`` fp16."""
         assert x.is_cuda and x.dtype == torch.float16 and x.is_contiguous() and tuple(x.shape) == (self.B, 3, self.H, self.W)
         self._in_ptr = C.c_void_p(x.data_ptr())
-        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        for step in self._steps:
-            step(stream)
+        main = torch.cuda.current_stream()
+        stream = C.c_void_p(main.cuda_stream)
+        if not (self.concurrent_heads and self._forks):
+            for step in self._steps:
+                step(stream)
+            return self.out
+        # fork / join over events: works eagerly and inside a stream capture (the side streams join the capture through
+        # the fork events and leave it through the join events)
+        for lane in self._forks:
+            if lane not in self._side:
+                self._side[lane] = (torch.cuda.Stream(device=self.dev), torch.cuda.Event(), torch.cuda.Event())
+        started = set()
+        for i, step in enumerate(self._steps):
+            for lane, pt in self._forks.items():
+                if pt == i:
+                    self._side[lane][1].record(main)              # everything before step i on the main stream is done
+            lane = self._lane_of[i]
+            if lane == 0:
+                step(stream)
+            else:
+                side, fork_ev, _ = self._side[lane]
+                if lane not in started:
+                    side.wait_event(fork_ev)
+                    started.add(lane)
+                step(C.c_void_p(side.cuda_stream))
+        for lane in started:
+            side, _, join_ev = self._side[lane]
+            join_ev.record(side)
+            main.wait_event(join_ev)
         return self.out
 
     def use_output(self, index: int) -> torch.Tensor:

@@ -371,7 +371,8 @@ class PipelinedTicks:
     the :class:`TickResult` instead.  Both raise if the device reported an overflow (tracker capacity / NMS capacity).
     """
 
-    def __init__(self, pipe: TickPipeline, depth: int = 2, use_graph: bool = True, overlap: bool = True):
+    def __init__(self, pipe: TickPipeline, depth: int = 2, use_graph: bool = True, overlap: bool = True,
+                 net_graph: bool = False):
         if any(not hasattr(d, "predict_batch_device") for d in pipe.detectors):
             raise NotImplementedError("PipelinedTicks needs detectors with a batched device path (temporal heads return host "
                                       "detections: use TickPipeline.tick)")
@@ -382,6 +383,11 @@ class PipelinedTicks:
         self.world_sharded = pipe.id_sync is not None
         fused = all(d.engine == "fused" and d.half and d._infer_fn is None for d in pipe.detectors)
         self.use_graph = bool(use_graph) and fused
+        # The network itself is launched eagerly by default: its plan forks the detect branches onto side streams, which
+        # run concurrently when launched eagerly but are serialised by the hipGraph executor of this ROCm (measured:
+        # 17.2 k vs 16.0 k frames/s); ~75 launches per tick cost the host ~0.3 ms of a 1.9 ms tick.  The latency-bound
+        # tail on stream B (K2/K3 -> K4 -> ids -> snapshot) is what the captured graph is for.
+        self.net_graph = bool(net_graph) and self.use_graph
         # ``overlap=False`` keeps everything on one stream (eager only): the per-stage timing pass of bench.py
         self.two_streams = (overlap or self.use_graph) and fused              # needs per-parity head tensors
         self.sA = torch.cuda.current_stream()
@@ -440,12 +446,13 @@ class PipelinedTicks:
             fp = self._plan_of(det, tensors[gi])
             pair = []
             for par in (0, 1):
-                fp.use_output(2 * gi + par)
-                gr = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gr):
-                    with torch.inference_mode():
-                        raws[gi][par] = det._infer(tensors[gi])    # network only, writes head tensor (group, parity)
-                pair.append(gr)
+                raws[gi][par] = fp.use_output(2 * gi + par)        # head tensor (group, parity): a stable buffer of the plan
+                if self.net_graph:
+                    gr = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gr):
+                        with torch.inference_mode():
+                            det._infer(tensors[gi])                # network only, writes that head tensor
+                    pair.append(gr)
             self._net_graphs.append(pair)
         torch.cuda.synchronize()
         for par in (0, 1):
@@ -511,7 +518,7 @@ class PipelinedTicks:
                 if k >= 2:
                     self.sA.wait_event(self._done[par])            # tick k-2 has finished reading the head tensors `par`
             tensors.append(tensor); metas.append(meta)
-            if replay:
+            if replay and self.net_graph:
                 self._net_graphs[gi][par].replay()
             else:
                 with torch.inference_mode():
