@@ -64,7 +64,9 @@ class FusedYoloV8:
         self._steps: List[Callable[[C.c_void_p], None]] = []
         self._lane_of: List[int] = []       # per step: 0 = main stream, k > 0 = side stream k (detect-head branches)
         self._lane = 0
-        self._forks: Dict[int, int] = {}    # side lane -> index of the first step that runs on it (fork point)
+        import os
+        self._split_branches = os.environ.get("RVA_HEAD_SPLIT", "0") == "1"     # measured: no gain over one lane per level (tools/bench_cmp.sh)
+        self._forks: Dict[int, Tuple[int, int]] = {}   # side lane -> (parent lane, step index at which it forks off the parent)
         self._tunable = []
         self._build(net)
         self._lane_of += [self._lane] * (len(self._steps) - len(self._lane_of))
@@ -216,8 +218,6 @@ class FusedYoloV8:
         point of this call (everything appended before it on the main lane is its dependency) and joins at the end."""
         self._lane_of += [self._lane] * (len(self._steps) - len(self._lane_of))
         self._lane = lane
-        if lane and lane not in self._forks:
-            self._forks[lane] = len(self._steps)
 
     # -- the graph ------------------------------------------------------------------------------------
     def _build(self, net: YoloV8):
@@ -297,11 +297,10 @@ class FusedYoloV8:
             # result: the stride-8 branch (the big one) runs on a side stream beside the rest of the neck -- h16 ... h21
             # are 40x40 / 20x20 layers that leave most CUs idle -- and the stride-16 branch beside h19 / h21; they join
             # the main stream at the end of the plan.  Only when the decode is fused into the branches (no k_head3).
-            if fuse_head and lvl < 2:
-                self._set_lane(lvl + 1)
-                self._forks[lvl + 1] = fork_n3 if lvl == 0 else fork_m4
-            else:
-                self._set_lane(0)
+            primary = lvl + 1 if (fuse_head and lvl < 2) else 0
+            self._set_lane(primary)
+            if primary:
+                self._forks[primary] = (0, fork_n3 if lvl == 0 else fork_m4)
             box, cls = net.detect.box[lvl], net.detect.cls[lvl]
             m = B * hh * ww
             cb = box[0].conv.out_channels
@@ -316,8 +315,15 @@ class FusedYoloV8:
             ko = _View(self._buf(m, self.nc), 0, self.nc)
             self._conv([box[0], cls[0]], feat, first, hh, ww)
             if fuse_head:
+                # box and class sub-branches are independent after the shared first convolution: the class one gets a
+                # lane of its own
+                fork_cls = len(self._steps)
                 self._conv(box[1], b1, b2, hh, ww); self._conv_head(box[2], b2, 1, hh, ww, a0, stride)
+                if self._split_branches:
+                    self._set_lane(4 + lvl)
+                    self._forks[4 + lvl] = (primary, fork_cls)
                 self._conv(cls[1], k1, k2, hh, ww); self._conv_head(cls[2], k2, 2, hh, ww, a0, stride)
+                self._set_lane(primary)
             else:
                 self._conv(box[1], b1, b2, hh, ww); self._conv(box[2], b2, bo, hh, ww)
                 self._conv(cls[1], k1, k2, hh, ww); self._conv(cls[2], k2, ko, hh, ww)
@@ -386,10 +392,13 @@ class FusedYoloV8:
             if lane not in self._side:
                 self._side[lane] = (torch.cuda.Stream(device=self.dev), torch.cuda.Event(), torch.cuda.Event())
         started = set()
+
+        def stream_of(lane):
+            return main if lane == 0 else self._side[lane][0]
         for i, step in enumerate(self._steps):
-            for lane, pt in self._forks.items():
+            for lane, (parent, pt) in self._forks.items():
                 if pt == i:
-                    self._side[lane][1].record(main)              # everything before step i on the main stream is done
+                    self._side[lane][1].record(stream_of(parent))  # everything the parent lane has been given so far is done
             lane = self._lane_of[i]
             if lane == 0:
                 step(stream)
