@@ -1886,7 +1886,7 @@ struct S2Args {
     const __half *w; const float *bias;
     __half *out; int ldo;
     const __half *res; int ldr;
-    int B, H, W, Ho, Wo, Cout, CoutPad, act, tiles_x, tiles_y, total;
+    int B, H, W, Ho, Wo, Cout, CoutPad, act, tiles_x, tiles_y, total, n_tiles;
 };
 
 template <int STRIDE, int CIN, int CO, int NWV, int NBUF, int RPW = 1>
@@ -1915,6 +1915,11 @@ __global__ void __launch_bounds__(NWV * 64) k_conv3_patch(S2Args a)
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lrow = lane / LPR, lp = lane % LPR;
     const int tiles_img = a.tiles_x * a.tiles_y;
+    // output channels are split into n_tiles groups of CO (each block keeps ITS group's weights resident): the layers whose
+    // whole weight tensor leaves room for one block per CU only run as two half-width blocks per CU that overlap each
+    // other's load / MFMA / SiLU / store phases
+    const int n0 = (int)(blockIdx.x % a.n_tiles) * CO;
+    const int bid = blockIdx.x / a.n_tiles, nblk = gridDim.x / a.n_tiles;
     // source chunk (x8 halfs) of LDS row `row`, physical chunk lp: inverse of the swizzle the fragment reads apply
     auto src_c8 = [&](int row) { return (CIN == 64 ? (lp ^ (row & 7)) : ((lp - 2 * (row >> 2)) & 3)) * 8; };
     // half offset of (row, 16-byte chunk c) inside a swizzled buffer
@@ -1922,7 +1927,7 @@ __global__ void __launch_bounds__(NWV * 64) k_conv3_patch(S2Args a)
 
     float4 bvs[FN];
 #pragma unroll
-    for (int i = 0; i < FN; ++i) bvs[i] = *reinterpret_cast<const float4 *>(a.bias + min(16 * i + (lane >> 4) * 4, a.CoutPad - 4));
+    for (int i = 0; i < FN; ++i) bvs[i] = *reinterpret_cast<const float4 *>(a.bias + min(n0 + 16 * i + (lane >> 4) * 4, a.CoutPad - 4));
 
     // weights: once per block
 #pragma unroll
@@ -1930,7 +1935,7 @@ __global__ void __launch_bounds__(NWV * 64) k_conv3_patch(S2Args a)
         const int idx = wv + NWV * k;
         if (idx < WPIECES) {
             const int row = idx * RPP + lrow;                       // row = tap * CO + co
-            const int tap = row / CO, co = min(row - tap * CO, a.CoutPad - 1);
+            const int tap = row / CO, co = min(n0 + row - tap * CO, a.CoutPad - 1);
             const __half *src = a.w + (size_t)(co * 9 + tap) * CIN + src_c8(row);
             __builtin_amdgcn_global_load_lds((glb_vptr)src, (lds_vptr)(wl + idx * 512), 16, 0, 0);
         }
@@ -1973,15 +1978,15 @@ __global__ void __launch_bounds__(NWV * 64) k_conv3_patch(S2Args a)
     int st_n = 0;
 #endif
     int pb = 0;
-    if (NBUF == 2 && (int)blockIdx.x < a.total) issue_patch(blockIdx.x, 0);
-    for (int t = blockIdx.x; t < a.total; t += gridDim.x) {
+    if (NBUF == 2 && bid < a.total) issue_patch(bid, 0);
+    for (int t = bid; t < a.total; t += nblk) {
         STAMP(0);
         if (NBUF == 1) issue_patch(t, 0);
         wait_vm<0>();
         STAMP(1);
         __builtin_amdgcn_s_barrier();        // this tile's patch (and the weights) are in LDS; the previous tile is done
         STAMP(2);
-        if (NBUF == 2 && t + (int)gridDim.x < a.total) issue_patch(t + gridDim.x, pb ^ 1);
+        if (NBUF == 2 && t + nblk < a.total) issue_patch(t + nblk, pb ^ 1);
         STAMP(3);
         const __half *patch = patch0 + (size_t)pb * PPIECES * 512;
         __half *stage = patch0 + (size_t)pb * PPIECES * 512;       // [TH*TW][SROW], once the patch is dead
@@ -2050,7 +2055,7 @@ __global__ void __launch_bounds__(NWV * 64) k_conv3_patch(S2Args a)
         STAMP(6);
         __syncthreads();
         STAMP(7);
-        const int cpr = a.Cout >> 3;
+        const int cpr = min(CO, a.Cout - n0) >> 3;
         for (int q = tid; q < TH * TW * cpr; q += NT) {
             const int px = q / cpr, pc = q - px * cpr;
             const int yy = ty * TH + px / TW, xx = tx * TW + px % TW;
@@ -2058,7 +2063,7 @@ __global__ void __launch_bounds__(NWV * 64) k_conv3_patch(S2Args a)
                 uint4 v = *reinterpret_cast<const uint4 *>(stage + (size_t)px * SROW + pc * 8);
                 const size_t m = (size_t)(b * a.Ho + yy) * a.Wo + xx;
                 if (a.res) {
-                    const uint4 r = *reinterpret_cast<const uint4 *>(a.res + m * a.ldr + pc * 8);
+                    const uint4 r = *reinterpret_cast<const uint4 *>(a.res + m * a.ldr + n0 + pc * 8);
                     __half2 *vh = reinterpret_cast<__half2 *>(&v);
                     const __half2 *rh = reinterpret_cast<const __half2 *>(&r);
 #pragma unroll
@@ -2067,7 +2072,7 @@ __global__ void __launch_bounds__(NWV * 64) k_conv3_patch(S2Args a)
                         vh[u] = __floats2half2_rn(x.x + y.x, x.y + y.y);
                     }
                 }
-                *reinterpret_cast<uint4 *>(a.out + m * a.ldo + pc * 8) = v;
+                *reinterpret_cast<uint4 *>(a.out + m * a.ldo + n0 + pc * 8) = v;
             }
         }
         STAMP(8);
@@ -2087,14 +2092,18 @@ hipError_t launch_patch(S2Args &g, int num_cus, hipStream_t s)
     if (hipError_t e = rva_func_smem((const void *)k_conv3_patch<STRIDE, CIN, CO, NWV, NBUF, RPW>, smem); e != hipSuccess) return e;
     g.tiles_x = rva_ceil_div(g.Wo, 32); g.tiles_y = rva_ceil_div(g.Ho, TH);
     g.total = g.tiles_x * g.tiles_y * g.B;
-    const int grid = g.total < per_cu * num_cus ? g.total : per_cu * num_cus;
+    g.n_tiles = rva_ceil_div(g.Cout, CO);
+    int per_n = per_cu * num_cus / g.n_tiles;                  // persistent blocks per channel group
+    if (per_n > g.total) per_n = g.total;
+    if (per_n < 1) per_n = 1;
+    const int grid = per_n * g.n_tiles;
     k_conv3_patch<STRIDE, CIN, CO, NWV, NBUF, RPW><<<grid, NWV * 64, smem, s>>>(g);
     return hipGetLastError();
 }
 
 }  // namespace
 
-#define RVA_CONV_VARIANTS 60
+#define RVA_CONV_VARIANTS 63
 
 extern "C" {
 #ifdef RVA_ROW_STAMPS
@@ -2170,7 +2179,7 @@ int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *wei
             if (rc == RVA_OK) return rc;
         }
     }
-    if (variant >= 52) {
+    if (variant >= 52 && variant <= 60) {
         // "long run" LDS-DMA kernels (3x3 stride 1, Cin % 32 == 0): a chunk's activation run staged once for all three dy
         hipError_t ev = hipErrorInvalidValue;
         if (ksize == 3 && stride == 1) {
@@ -2210,6 +2219,10 @@ int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *wei
             else if (variant == 49) ev = launch_patch<1, 64, 64, 8, 2>(g, num_cus, s);    // 158 KB: eight waves, two patch buffers
             else if (variant == 50) ev = launch_patch<1, 64, 64, 4, 2, 2>(g, num_cus, s); // 158 KB: four waves x two rows, two buffers
             else if (variant == 51) ev = launch_patch<1, 64, 64, 8, 1, 2>(g, num_cus, s); // 149 KB: 16-row tile, eight waves x two rows
+            // output channels in two groups of 32: 36 KB of weights per block, two blocks per CU
+            else if (variant == 61) ev = launch_patch<1, 64, 32, 8, 1, 1>(g, num_cus, s); // 79 KB: 8-row tile
+            else if (variant == 62) ev = launch_patch<1, 64, 32, 4, 1, 1>(g, num_cus, s); // 62 KB: 4-row tile
+            else if (variant == 63) ev = launch_patch<1, 64, 32, 4, 1, 2>(g, num_cus, s); // 79 KB: 8-row tile, four waves x two rows
         }
         if (ev == hipSuccess) return RVA_OK;
         (void)hipGetLastError();

@@ -196,7 +196,9 @@ def test_upcat_conv_matches_torch(shape):
 @pytest.mark.parametrize("shape", [(2, 21, 18, 64, 43), (1, 160, 160, 64, 43), (3, 33, 71, 32, 43), (2, 8, 64, 64, 43),
                                    (2, 21, 18, 32, 44), (1, 160, 160, 32, 45), (3, 33, 71, 32, 45), (2, 7, 64, 16, 44),
                                    (2, 21, 18, 64, 46), (1, 80, 80, 64, 46), (3, 33, 71, 64, 47), (2, 7, 64, 32, 48), (4, 40, 40, 64, 48),
-                                   (2, 80, 80, 64, 49), (3, 19, 45, 64, 49), (2, 80, 80, 64, 50), (3, 19, 45, 32, 50), (2, 80, 80, 64, 51), (3, 19, 45, 64, 51)])
+                                   (2, 80, 80, 64, 49), (3, 19, 45, 64, 49), (2, 80, 80, 64, 50), (3, 19, 45, 32, 50), (2, 80, 80, 64, 51), (3, 19, 45, 64, 51),
+                                   # output channels in two resident groups of 32 (two blocks per CU), incl. Cout that fills 1.5 groups
+                                   (2, 80, 80, 64, 61), (3, 19, 45, 48, 61), (2, 21, 18, 64, 62), (3, 33, 71, 40, 62), (2, 80, 80, 64, 63), (3, 19, 45, 32, 63)])
 def test_patch_kernels_match_torch(shape):
     """Variants 43-51: the resident-weight patch kernels (Cin = 32: 3x3 stride 2 -> Cout <= 64, stride 1 -> Cout <= 32; Cin = 64: stride 1 -> Cout <= 64),
     odd sizes, partial tiles, residual on the stride-1 form, an output slice with a row stride."""

@@ -22,8 +22,9 @@ for spec in "128 128 3 1 40 32 56" "128 128 3 1 40 32 27" "64 64 3 1 80 32 51" "
 done
 cd $ROOT
 python3 tools/summarize_profile.py $OUT/bench $OUT/bench_kernel_stats_summary.csv "bench.py --steps 100 --warmup 20, round 2" > /dev/null
+python3 tools/tick_breakdown.py $OUT/bench 90 > $OUT/tick_breakdown.csv; head -45 $OUT/tick_breakdown.csv
 python3 tools/pmc_summary.py $OUT/k1_FETCH_SIZE $OUT/k1_WRITE_SIZE > $OUT/k1_pmc_summary.txt
 for j in 1 2 3 4 5 6; do echo "== conv$j: $(tail -1 $OUT/conv${j}_a.log)"; python3 tools/pmc_summary.py $OUT/conv${j}_a $OUT/conv${j}_b; done > $OUT/conv_pmc_summary.txt
 # keep the merge small: drop raw traces, keep summaries + stats
 find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*.db" -delete
-du -sh $OUT; cat $OUT/k1_pmc_summary.txt; head -60 $OUT/conv_pmc_summary.txt
+du -sh $OUT
