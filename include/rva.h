@@ -364,6 +364,19 @@ int rva_resize_nv12_to_bgr_batch(rva_ctx *ctx, const void *const *y_ptrs, const 
                                  void *out_bgr, int dst_w, int dst_h, rva_stream_t stream);
 
 /* ----------------------------------------------------------------------------------------------
+ * K6 annotated preview -- replaces the pixel work of KafkaSink._render_frame (sinks/kafka_sink.py:200-294) and of
+ * StreamWorker._maybe_save_snapshot (pipeline.py:264-290): uint8 BGR image out_bgr[dst_h][dst_w][3] (device) =
+ * the NV12 surface converted (BT.601 as in K1), box-averaged down by the integer `ratio` (1 = same size; 0 = out_bgr
+ * already holds the base image, draw only), then `n_rects` filled rectangles (device int32[n][4] x0,y0,x1,y1
+ * inclusive, device uint8[n][4] b,g,r,-) in painter's order and `n_glyphs` characters of a built-in 5x7 font (device
+ * int32[m][3] x, y, code; digits, 'I', 'D', space) in white at `glyph_scale`.  WHAT is drawn is decided by the host
+ * (preview.py, pinned against a call-level recording of the reference); how OpenCV rasterises lines and glyphs is unpinned.
+ * -------------------------------------------------------------------------------------------- */
+int rva_preview_nv12(rva_ctx *ctx, const void *y, const void *uv, int pitch, int src_w, int src_h, int ratio,
+                     void *out_bgr, int dst_w, int dst_h, const int32_t *rects, const uint8_t *colors, int n_rects,
+                     const int32_t *glyphs, int n_glyphs, int glyph_scale, rva_stream_t stream);
+
+/* ----------------------------------------------------------------------------------------------
  * D1 decode -- stands where VideoStream.open()/frames() sit on cv2.VideoCapture(url, CAP_FFMPEG) (video_stream.py:76,
  * 173): an H.264 / H.265 Annex-B elementary stream goes to the VCN decoder through rocDecode and comes back as NV12
  * surfaces in HBM (device pointers + pitch, the input form of rva_preprocess_nv12_batch); no frame visits the host.

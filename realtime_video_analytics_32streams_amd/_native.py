@@ -19,7 +19,7 @@ ROOT = PKG.parent
 CSRC = PKG / "csrc"
 LIB_PATH = PKG / "librva.so"
 SOURCES = ["rva_ctx.hip", "rva_preprocess.hip", "rva_postprocess.hip", "rva_tracker.hip", "rva_conv.hip", "rva_gates.hip",
-           "rva_decode.hip"]
+           "rva_decode.hip", "rva_preview.hip"]
 # -ffp-contract=off: parity kernels must not fuse a*b+c (SURVEY.md hard part 4)
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off",
                "-Wall", "-Wno-unused-function"]
@@ -126,6 +126,8 @@ def lib() -> C.CDLL:
         "rva_tracker_snapshot_fetch": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
         "rva_tracker_state": (C.c_int, [_P, i64p, C.POINTER(C.c_int), _P]),
         "rva_tracker_set_next_id": (C.c_int, [_P, C.c_int64, _P]),
+        "rva_preview_nv12": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P, _P, C.c_int, _P, C.c_int,
+                                       C.c_int, _P]),
         "rva_decode_available": (C.c_int, [C.c_char_p, C.c_int]),
         "rva_decoder_create": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(_P)]),
         "rva_decoder_destroy": (None, [_P]),
@@ -173,7 +175,7 @@ EXPORTS = [
     "rva_tracker_set_gates", "rva_tracker_snapshot_status", "rva_tracker_new_counts",
     "rva_tracker_assign_ids", "rva_tracker_read", "rva_tracker_read_all", "rva_tracker_snapshot_async",
     "rva_tracker_snapshot_fetch", "rva_tracker_state",
-    "rva_tracker_set_next_id", "rva_decode_available", "rva_decoder_create", "rva_decoder_destroy", "rva_decoder_feed",
+    "rva_tracker_set_next_id", "rva_preview_nv12", "rva_decode_available", "rva_decoder_create", "rva_decoder_destroy", "rva_decoder_feed",
     "rva_decoder_next_frame", "rva_decoder_release", "rva_motion_nv12_batch", "rva_motion_nv12_masked_batch", "rva_motion_bgr_batch",
     "rva_preprocess_nv12_masked_batch", "rva_resize_nv12_to_bgr_batch", "rva_tracker_set_box_scale", "rva_conv_cout_pad", "rva_conv_num_variants", "rva_conv2d_nhwc_f16", "rva_conv2d_nhwc_f16_v", "rva_stem_conv_f16",
     "rva_conv1x1_head_f16", "rva_conv1x1_upcat_f16", "rva_sppf_pool3_nhwc_f16", "rva_maxpool5_nhwc_f16", "rva_upsample2x_nhwc_f16", "rva_yolo_head_f16", "rva_yolo_head3_f16",

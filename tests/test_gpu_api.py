@@ -331,3 +331,39 @@ def test_temporal_networks_match_reference_logits(idx):
         top = np.argsort(want[0], kind="stable")[-5:][::-1]
         assert [d.class_id for d in dets] == top.tolist()
         assert np.allclose([d.confidence for d in dets], want[0][top], atol=1e-3)
+
+
+def test_preview_render_matches_its_raster_rule_and_encodes():
+    """K6 (rva_preview_nv12): the annotated preview of a 4K surface (2x2 box mean down to 1080p -- OpenCV's INTER_AREA rule
+    at an integer ratio) and of a 1080p surface (no resize) against a numpy restatement of this module's raster rule
+    (inclusive filled rectangles in painter's order, 5x7 glyphs); then the frame_jpeg data URL decodes to that image.
+    The drawing PLAN is pinned by the reference recording (tests/test_wire.py); the raster itself is unpinned (cv2 absent)."""
+    import base64, io
+    from PIL import Image
+    from realtime_video_analytics_32streams_amd import preview as P
+    for (w, h) in ((3840, 2160), (1920, 1080)):
+        y, uv = synth.make_nv12(5, w, h, ((w + 255) // 256) * 256)
+        surf = ops.Nv12Surface.from_numpy(y, uv, w, h)
+        tracks = [{"track_id": 7, "class_id": 2, "confidence": 0.9, "bbox_xyxy": [100.7, 80.2, 900.4, 700.9]},
+                  {"track_id": 1234, "class_id": 33, "confidence": 0.8, "bbox_xyxy": [w - 300.0, 2.0, w - 2.0, 400.0]},
+                  {"track_id": 56, "class_id": 0, "confidence": 0.7, "bbox_xyxy": [500.0, 300.0, 1200.0, 1000.0]}]
+        plan = P.plan_render((w, h), tracks, 85)
+        got = P.render_nv12(surf, plan).cpu().numpy()
+        tw, th = (1920, 1080)
+        assert got.shape == (th, tw, 3)
+        bgr = orc.nv12_to_bgr(y, uv, w, h).astype(np.int32)
+        if w == 3840:
+            bgr = (bgr[0::2, 0::2] + bgr[0::2, 1::2] + bgr[1::2, 0::2] + bgr[1::2, 1::2] + 2) // 4
+        want = bgr.astype(np.uint8)
+        rects, colors, glyphs = P.raster_primitives(plan, (tw, th))
+        assert len(rects) == 3 * 5 and len(glyphs) == len("ID 7") + len("ID 1234") + len("ID 56")
+        for (x0, y0, x1, y1), c in zip(rects, colors):
+            want[y0:y1 + 1, x0:x1 + 1] = c[:3]
+        n_glyph_px = int(((got != want).any(-1)).sum())
+        assert 0 < n_glyph_px < 40 * 14 * len(glyphs)            # only glyph pixels differ from the rectangle-only image ...
+        diff = (got != want).any(-1)
+        assert (got[diff] == 255).all()                            # ... and they are white
+        url = P.render_frame(surf, tracks, 85)
+        assert url.startswith("data:image/jpeg;base64,")
+        back = np.asarray(Image.open(io.BytesIO(base64.b64decode(url.split(",", 1)[1]))).convert("RGB"))[..., ::-1]
+        assert back.shape == got.shape and np.abs(back.astype(int) - got.astype(int)).mean() < 4.0

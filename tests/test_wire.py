@@ -42,3 +42,46 @@ def test_consumer_side_parse():
     import pytest
     with pytest.raises(ValueError):
         wire.parse_event(json.dumps(bad))      # the dashboard schema rejects confidence > 1 (raw temporal logits can be)
+
+
+def test_preview_plan_and_policy_match_reference_recording():
+    """8f-3 host logic against tests/golden/preview_plan.json, recorded from the reference's own KafkaSink with a call-level
+    cv2 recorder: every resize / rectangle / text / encode operation of _render_frame (target size, integer coordinates,
+    colours, thickness, label text and origin, encoder parameters), the adaptive quality table, the per-class colours and
+    the 10-per-second rate limit."""
+    from realtime_video_analytics_32streams_amd import preview as P
+    from tests.conftest import load_golden
+    g = load_golden("preview_plan.json")
+    scripted = lambda label: ((9 * len(label), 11), 4)            # noqa: E731  the recorder's getTextSize rule
+    for r in g["render"]:
+        ops = P.plan_render(tuple(r["wh"]), r["tracks"], r["quality"], r["webp"], text_size=scripted)
+        assert ops == r["calls"], (r["wh"], len(r["tracks"]))
+        mime = "image/webp" if ops[-1][1] == ".webp" else "image/jpeg"
+        assert r["url"].startswith(f"data:{mime};base64,")
+    for q in g["quality"]:
+        pol = P.PreviewPolicy(frame_quality=q["base"])
+        assert [pol.adaptive_quality(c) for c in range(16)] == q["by_count"]
+    assert [[c, list(P.color_for(c))] for c, _ in g["colors"]] == g["colors"]
+    now = [0.0]
+    pol = P.PreviewPolicy(clock=lambda: now[0])
+    got = []
+    for name, t, _ in g["rate"]:
+        now[0] = t
+        got.append([name, t, pol.should_send_frame(name)])
+    assert got == g["rate"]
+
+
+def test_preview_encoder_roundtrip_on_host():
+    """The host encoder (Pillow standing in for cv2.imencode): a data URL whose payload decodes back to the image."""
+    import base64, io
+    import numpy as np
+    from PIL import Image
+    from realtime_video_analytics_32streams_amd import preview as P
+    rng = np.random.default_rng(3)
+    img = np.zeros((72, 128, 3), np.uint8)
+    img[..., 0] = np.linspace(0, 255, 128)[None, :]; img[..., 1] = np.linspace(0, 255, 72)[:, None]; img[20:40, 30:90, 2] = 200
+    for ext, params in ((".jpg", [P.IMWRITE_JPEG_QUALITY, 90, P.IMWRITE_JPEG_PROGRESSIVE, 1, P.IMWRITE_JPEG_OPTIMIZE, 1]),
+                        (".webp", [P.IMWRITE_WEBP_QUALITY, 90])):
+        data, mime = P.encode_image(img, ext, params)
+        back = np.asarray(Image.open(io.BytesIO(data)).convert("RGB"))[..., ::-1]
+        assert back.shape == img.shape and np.abs(back.astype(int) - img.astype(int)).mean() < 6.0, (ext, mime)
