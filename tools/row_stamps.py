@@ -39,7 +39,7 @@ cpad = (cout + 63) // 64 * 64
 w = torch.randn((cpad, 9, cinp), device="cuda").half() * 0.05
 b = torch.zeros(cpad, device="cuda")
 L.rva_conv2d_nhwc_f16_v.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int] + [C.c_int] * 8 + [C.c_int, C.c_void_p]
-fn = lambda: L.rva_conv2d_nhwc_f16_v(ctx, x.data_ptr(), cin, w.data_ptr(), b.data_ptr(), out.data_ptr(), cout, None, 0, B, H, H, cin, cout, 3, 1, 1, variant, s)
+fn = lambda: L.rva_conv2d_nhwc_f16_v(ctx, x.data_ptr(), cin, w.data_ptr(), b.data_ptr(), out.data_ptr(), cout, None, 0, B, H, H, cin, cout, 3, 1, int(os.environ.get('RVA_ACT', '1')), variant, s)
 for _ in range(3):
     assert fn() == 0
 torch.cuda.synchronize()
