@@ -315,6 +315,17 @@ int rva_conv1x1_head_f16(rva_ctx *ctx, const void *in, int ldi, const void *weig
                          int anchor_offset, float stride_px, int variant, rva_stream_t stream);
 int rva_stem_conv_f16(rva_ctx *ctx, const void *in_planar, const void *weights, const float *bias,
                       void *out, int ldo, int batch, int H, int W, int Cout, rva_stream_t stream);
+
+/* rva_stem2_f16: the stem and the first downsampling convolution of YOLOv8s (3 -> 32 -> 64 channels, both 3x3 stride 2
+ * pad 1 with bias + SiLU; ultralytics model.0 and model.1, reference call site detector.py:597-609 via the exported graph)
+ * in ONE launch: the half-resolution 32-channel tensor stays in LDS.  in_planar, w1 ([64][32] fp16, column order of
+ * rva_stem_conv_f16) and b1 ([64] fp32) as for rva_stem_conv_f16 with Cout = 32; w2 / b2 in the layout of
+ * rva_conv2d_nhwc_f16 for Cin = 32, Cout = 64 ([64][9][32] fp16, [64] fp32); out: NHWC fp16 [batch, Ho, Wo, 64] with row
+ * stride ldo (>= 64, multiple of 8), Ho = ((H-1)/2)/2 + 1.  W % 8 == 0.  Results equal stem -> conv up to fp32 summation
+ * order inside the stem's 27-tap dot product. */
+int rva_stem2_f16(rva_ctx *ctx, const void *in_planar, const void *w1, const float *b1, const void *w2, const float *b2,
+                  void *out, int ldo, int batch, int H, int W, rva_stream_t stream);
+
 /* SPPF's three chained 5x5/1 max pools in one launch: out1 = pool5(in), out2 = pool5(out1) = pool9(in),
  * out3 = pool5(out2) = pool13(in) (stride 1, -inf padding), all three with row stride ldo.  H*W*64 bytes must fit LDS
  * (H*W <= 2400); larger maps use rva_maxpool5_nhwc_f16 three times. */

@@ -2101,6 +2101,258 @@ hipError_t launch_patch(S2Args &g, int num_cus, hipStream_t s)
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Stem + first downsampling convolution in ONE launch, for the YOLOv8s widths (3 -> 32 -> 64, both 3x3 stride 2, SiLU).
+//
+// As two launches the pair moves 78 MB in, 210 MB out (stem), 210 MB in again and 105 MB out: 600 MB per 32-frame batch,
+// 160 us of an HBM-bound 1.9 ms tick.  Fused, the 32-channel half-resolution tensor never leaves the CU.  Persistent
+// blocks (one per CU, sixteen waves) walk 4 x 32 output tiles as a two-stage pipeline of wave groups, two waves of each
+// group per SIMD, ONE workgroup barrier per tile:
+//   waves 0-7 (stage S, vector-ALU bound: 585 x 32 SiLUs per tile)   tile k+1
+//      the 3 x 19 x 136 planar input patch (prefetched into registers one tile ahead) sits in LDS; the 9 x 65 stem pixels
+//      under the tile are computed by MFMA straight from it -- no im2col buffer: the K order is  k' = 4 * (c*3 + ky) + s
+//      with s = 0 a zero-weight slot and s = 1..3 = kx 0..2, so a pixel's four slots of a (c, ky) row are two aligned
+//      dwords of the patch row and a lane's eight K values are two such rows (K = 36 padded to 64: a second MFMA whose only
+//      live row is (c, ky) = (2, 2)); bias + SiLU, stem pixels outside the image written as zeros (they are the second
+//      convolution's padding), into the column-parity patch layout of k_conv3_patch<2, 32, 64>;
+//   waves 8-15 (stage C, MFMA bound: 36 MFMAs per wave)             tile k
+//      the second convolution on the patch the other group finished one tile ago, exactly as k_conv3_patch does it
+//      (weights resident, tap-major), then bias + SiLU -> a wave-private stage -> 16-byte row stores.
+// Patch and input buffers are double-buffered between the groups.
+struct Stem2Args {
+    const __half *in; const __half *w1; const float *b1; const __half *w2; const float *b2; __half *out; int ldo;
+    int B, H, W, H1, W1, Ho, Wo, tiles_x, tiles_y, total;
+};
+
+constexpr int S2_TH = 4, S2_TW = 32;
+constexpr int S2_PROWS = (2 * S2_TH + 1) * 2 * (S2_TW + 1);                  // 9 x 65 stem pixels as two column-parity planes
+constexpr int S2_IR = 4 * S2_TH + 3, S2_IC = 136;                            // input patch: rows per plane, halfs per row
+constexpr int S2_SROW = 64 + 8;
+constexpr size_t S2_SMEM = (size_t)36 * 1024 + 2 * (size_t)(S2_PROWS + 1) * 64 + 2 * (size_t)3 * S2_IR * S2_IC * 2 + (size_t)S2_TH * S2_TW * S2_SROW * 2;
+static_assert(S2_SMEM <= 160 * 1024, "LDS budget");
+
+__global__ void __launch_bounds__(1024) k_stem2(Stem2Args a)
+{
+    constexpr int TH = S2_TH, TW = S2_TW, CW = TW + 1, PROWS = S2_PROWS, WPIECES = 9 * 64 / 16;
+    constexpr int IR = S2_IR, IC = S2_IC;
+    constexpr int NCH = 3 * IR * (IC / 8), NPV = (NCH + 511) / 512;           // 16-byte chunks of the input patch, per thread of group S
+    constexpr int SPX = (2 * TH + 1) * (2 * TW + 1), NFR = (SPX + 15) / 16;   // stem pixels / fragments of a patch
+    constexpr int SROW = S2_SROW, FN = 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __half *wl = (__half *)smem;                           // [9 taps][64][32]   second convolution, swizzled rows
+    __half *patch0 = wl + WPIECES * 512;                   // [2][PROWS + 1][32] stem output (+ a dump row for lanes without a pixel)
+    __half *inp0 = patch0 + 2 * (PROWS + 1) * 32;                // [2][3][IR][IC]     planar input patch
+    __half *stage0 = inp0 + 2 * 3 * IR * IC;               // [TH*TW][SROW]      output stage, rows private to a wave
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, q = lane >> 4;
+    const int tiles_img = a.tiles_x * a.tiles_y;
+    const int nk = ((int)a.total - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;      // tiles of this block
+
+    // second convolution's weights: once per block, by LDS-DMA (row = tap * 64 + co)
+    {
+        const int lrow = lane >> 2, lp = lane & 3;
+#pragma unroll
+        for (int k = 0; k < (WPIECES + 15) / 16; ++k) {
+            const int idx = wv + 16 * k;
+            if (idx < WPIECES) {
+                const int row = idx * 16 + lrow;
+                const int tap = row >> 6, co = row & 63;
+                const __half *src = a.w2 + (size_t)(co * 9 + tap) * 32 + ((lp - 2 * (row >> 2)) & 3) * 8;
+                __builtin_amdgcn_global_load_lds((glb_vptr)src, (lds_vptr)(wl + idx * 512), 16, 0, 0);
+            }
+        }
+    }
+#ifdef RVA_ROW_STAMPS
+    const int st_stride = gridDim.x / 8;
+    const bool st_on = (tid == 0 || tid == 512) && st_stride > 0 && blockIdx.x % st_stride == 0 && blockIdx.x / st_stride < 4;
+    const int st_slot = st_on ? (blockIdx.x / st_stride) * 2 + (tid >> 9) : 0;
+    int st_n = 0;
+#endif
+
+    if (wv < 8) {
+        // ---------------- stage S: input patch -> stem pixels -> patch[k & 1] ----------------
+        // stem weights as A fragments in registers.  API column order of w1 (see rva_stem_conv_f16): k = 2j + kx for kx in
+        // {0,1}, 18 + j for kx = 2, j = c*3 + ky.  The bias is the accumulator's initial value.
+        h8 af1[2], af2[2];
+        f4 bias1[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const __half *wr = a.w1 + (size_t)(16 * i + n) * 32;
+            const __half zero = __float2half(0.f);
+            __half t1[8], t2[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int j = 2 * q + (e >> 2), sl = e & 3, kx = sl - 1;
+                t1[e] = sl == 0 ? zero : wr[kx < 2 ? 2 * j + kx : 18 + j];
+                t2[e] = (q == 0 && e >= 1 && e < 4) ? wr[e - 1 < 2 ? 16 + (e - 1) : 26] : zero;
+            }
+            af1[i] = *reinterpret_cast<const h8 *>(t1);
+            af2[i] = *reinterpret_cast<const h8 *>(t2);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) bias1[i][u] = a.b1[16 * i + 4 * q + u];
+        }
+        // this lane's two (c, ky) rows of the first K step, as half offsets into the input patch
+        const int ro0 = (((2 * q) / 3) * IR + (2 * q) % 3) * IC, ro1 = (((2 * q + 1) / 3) * IR + (2 * q + 1) % 3) * IC;
+        constexpr int ro8 = (2 * IR + 2) * IC;
+        u4 pv[NPV];
+        auto prefetch = [&](int t) {
+            const int b = t / tiles_img, r2 = t - b * tiles_img, ty = r2 / a.tiles_x, tx = r2 - ty * a.tiles_x;
+            const int iy0 = 4 * ty * TH - 3, x00 = 4 * tx * TW - 8;
+#pragma unroll
+            for (int k = 0; k < NPV; ++k) {
+                const int c16 = tid + 512 * k;
+                const int row = c16 / 17, cx = c16 - row * 17;
+                const int c = row / IR, r = row - c * IR;
+                const int iy = iy0 + r, x0 = x00 + cx * 8;
+                pv[k] = u4{0u, 0u, 0u, 0u};
+                if (c16 < NCH && (unsigned)iy < (unsigned)a.H && (unsigned)x0 < (unsigned)a.W)
+                    pv[k] = *reinterpret_cast<const u4 *>(a.in + ((size_t)(b * 3 + c) * a.H + iy) * a.W + x0);
+            }
+        };
+        auto stage_input = [&](int buf) {
+            __half *inp = inp0 + (size_t)buf * 3 * IR * IC;
+#pragma unroll
+            for (int k = 0; k < NPV; ++k) {
+                const int c16 = tid + 512 * k;
+                if (c16 < NCH) *reinterpret_cast<u4 *>(inp + (size_t)(c16 / 17) * IC + (c16 % 17) * 8) = pv[k];
+            }
+        };
+        // geometry of this lane's pixel in each of the wave's fragments (the same for every tile): read offset into the input
+        // patch, (py << 8 | px), and the write offset of channel group 0 in the stem patch (group 1 = that ^ 16)
+        constexpr int FPW = (NFR + 7) / 8, UNR = FPW;
+        static_assert(FPW % UNR == 0, "fragments per wave");
+        int frd[FPW], fpp[FPW], fw[FPW];
+#pragma unroll
+        for (int e = 0; e < FPW; ++e) {
+            const int f = wv + 8 * e;
+            const int p = min(16 * f + n, SPX - 1);
+            const int py = p / (2 * TW + 1), px = p - py * (2 * TW + 1);
+            const int prow = (py * 2 + (px & 1)) * CW + (px >> 1);
+            frd[e] = (2 * py) * IC + 2 * px + 4;
+            fpp[e] = (py << 8) | px;
+            fw[e] = 16 * f + n < SPX ? swz32(prow, q >> 1) + 4 * (q & 1) : PROWS * 32 + 4 * (q & 1);      // no pixel: the dump row behind the patch
+        }
+        if (nk > 0) { prefetch(blockIdx.x); stage_input(0); }
+        __syncthreads();                                       // input patch of the first tile visible to the group
+        for (int k = 0; k <= nk; ++k) {                        // iteration k: this group works on tile k, the other on tile k - 1
+            STAMP(0);
+            if (k < nk) {
+                const int t = blockIdx.x + k * gridDim.x;
+                const int b = t / tiles_img, r2 = t - b * tiles_img, ty = r2 / a.tiles_x, tx = r2 - ty * a.tiles_x;
+                (void)b;
+                if (k + 1 < nk) prefetch(t + gridDim.x);
+                const __half *inp = inp0 + (size_t)(k & 1) * 3 * IR * IC;
+                __half *patch = patch0 + (size_t)(k & 1) * (PROWS + 1) * 32;
+                const int sy0 = 2 * ty * TH - 1, sx0 = 2 * tx * TW - 1;
+                // fragments in pairs: the chain  LDS read -> 2 dependent MFMAs -> exp / rcp -> LDS write  of one fragment is
+                // ~700 cycles of latency (tools/stem2_stamps.py); independent chains overlap
+                const int pyb = -sy0, pxb = -sx0;                     // first in-image patch row / column
+                const int pye = a.H1 - sy0, pxe = a.W1 - sx0;         // one past the last
+#pragma unroll
+                for (int g = 0; g < FPW / UNR; ++g) {
+                    h8 bf1[UNR], bf2[UNR];
+#pragma unroll
+                    for (int u = 0; u < UNR; ++u) {
+                        const __half *base = inp + frd[g * UNR + u];
+                        const uint32_t *d0 = reinterpret_cast<const uint32_t *>(base + ro0), *d1 = reinterpret_cast<const uint32_t *>(base + ro1);
+                        const uint32_t *d8 = reinterpret_cast<const uint32_t *>(base + ro8);
+                        uint32_t b1w[4] = {d0[0], d0[1], d1[0], d1[1]};
+                        uint32_t b2w[4] = {d8[0], d8[1], 0u, 0u};       // lanes q > 0 carry zero weights in af2: their (finite) data is ignored
+                        bf1[u] = *reinterpret_cast<const h8 *>(b1w);
+                        bf2[u] = *reinterpret_cast<const h8 *>(b2w);
+                    }
+                    f4 sacc[UNR][2];
+#pragma unroll
+                    for (int u = 0; u < UNR; ++u)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) sacc[u][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af1[i], bf1[u], bias1[i], 0, 0, 0);
+#pragma unroll
+                    for (int u = 0; u < UNR; ++u)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) sacc[u][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af2[i], bf2[u], sacc[u][i], 0, 0, 0);
+#pragma unroll
+                    for (int u = 0; u < UNR; ++u) {
+                        const int py = fpp[g * UNR + u] >> 8, px = fpp[g * UNR + u] & 255;
+                        const bool inimg = py >= pyb && py < pye && px >= pxb && px < pxe;
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            const float v0 = silu_f(sacc[u][i][0]), v1 = silu_f(sacc[u][i][1]), v2 = silu_f(sacc[u][i][2]), v3 = silu_f(sacc[u][i][3]);
+                            __half2 lo = __floats2half2_rn(v0, v1), hi = __floats2half2_rn(v2, v3);
+                            uint2 pk;
+                            pk.x = inimg ? *reinterpret_cast<uint32_t *>(&lo) : 0u;
+                            pk.y = inimg ? *reinterpret_cast<uint32_t *>(&hi) : 0u;
+                            *reinterpret_cast<uint2 *>(patch + (fw[g * UNR + u] ^ (16 * i))) = pk;     // lanes without a pixel: the dump row
+                        }
+                    }
+                }
+                STAMP(1);
+                if (k + 1 < nk) stage_input((k + 1) & 1);      // its last readers finished in iteration k - 1
+            } else { STAMP(1); }
+            STAMP(2);
+            __syncthreads();
+            STAMP(3);
+        }
+    } else {
+        // ---------------- stage C: patch[(k - 1) & 1] -> second convolution -> output tile ----------------
+        const int wb = wv - 8, orow = wb >> 1, ohalf = wb & 1;          // output row of the tile / 16-pixel half of it
+        float4 bvs[FN];
+#pragma unroll
+        for (int i = 0; i < FN; ++i) bvs[i] = *reinterpret_cast<const float4 *>(a.b2 + 16 * i + q * 4);
+        wait_vm<0>();                                          // this wave's share of the weights
+        __syncthreads();
+        __half *stage = stage0 + (size_t)wb * 16 * SROW;
+        for (int k = 0; k <= nk; ++k) {
+            STAMP(0);
+            if (k > 0) {
+                const int t = blockIdx.x + (k - 1) * gridDim.x;
+                const int b = t / tiles_img, r2 = t - b * tiles_img, ty = r2 / a.tiles_x, tx = r2 - ty * a.tiles_x;
+                const __half *patch = patch0 + (size_t)((k - 1) & 1) * (PROWS + 1) * 32;
+                f4 acc[FN];
+#pragma unroll
+                for (int i = 0; i < FN; ++i) acc[i] = f4{bvs[i].x, bvs[i].y, bvs[i].z, bvs[i].w};
+#pragma unroll
+                for (int tp = 0; tp < 9; ++tp) {
+                    const int dy = tp / 3, dx = tp % 3;
+                    const int rb = ((2 * orow + dy) * 2 + (dx & 1)) * CW + (dx >> 1) + 16 * ohalf + n;
+                    const h8 bf = *reinterpret_cast<const h8 *>(patch + swz32(rb, q));
+#pragma unroll
+                    for (int i = 0; i < FN; ++i) {
+                        const h8 af = *reinterpret_cast<const h8 *>(wl + swz32(tp * 64 + 16 * i + n, q));
+                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, acc[i], 0, 0, 0);
+                    }
+                }
+                STAMP(1);
+#pragma unroll
+                for (int i = 0; i < FN; ++i) {
+                    const int co = 16 * i + q * 4;
+                    const float v0 = silu_f(acc[i][0]), v1 = silu_f(acc[i][1]), v2 = silu_f(acc[i][2]), v3 = silu_f(acc[i][3]);
+                    __half2 lo = __floats2half2_rn(v0, v1), hi = __floats2half2_rn(v2, v3);
+                    uint2 pk;
+                    pk.x = *reinterpret_cast<uint32_t *>(&lo);
+                    pk.y = *reinterpret_cast<uint32_t *>(&hi);
+                    *reinterpret_cast<uint2 *>(stage + (size_t)n * SROW + co) = pk;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the stage rows are this wave's own: no barrier, just ordering
+                const int yy = ty * TH + orow;
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const int c16 = lane + 64 * it;
+                    const int opx = c16 >> 3, pc = c16 & 7;
+                    const int xx = tx * TW + 16 * ohalf + opx;
+                    if (yy < a.Ho && xx < a.Wo)
+                        *reinterpret_cast<uint4 *>(a.out + ((size_t)(b * a.Ho + yy) * a.Wo + xx) * a.ldo + pc * 8) =
+                            *reinterpret_cast<const uint4 *>(stage + (size_t)opx * SROW + pc * 8);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // stage reads done before the next tile's stage writes
+            } else { STAMP(1); }
+            STAMP(2);
+            __syncthreads();
+            STAMP(3);
+        }
+    }
+}
+
 }  // namespace
 
 #define RVA_CONV_VARIANTS 63
@@ -2457,6 +2709,31 @@ int rva_stem_conv_f16(rva_ctx *ctx, const void *in_planar, const void *weights, 
     if (grid > total_tiles) grid = total_tiles;
     if (W % 8 || ((uintptr_t)in_planar & 15)) return rva_fail(ctx, RVA_ERR_ARG, "rva_stem_conv_f16: W %% 8 == 0 and a 16-byte aligned input are required");
     k_stem<<<grid, 256, (size_t)(3 * 17 * 88 * 2) + (size_t)(256 * (Cout + 8 > LDSROW ? Cout + 8 : LDSROW) + 64 * LDSROW) * 2, (hipStream_t)stream_>>>(a, (const __half *)weights, bias);
+    RVA_HIP(ctx, hipGetLastError());
+    return RVA_OK;
+}
+
+int rva_stem2_f16(rva_ctx *ctx, const void *in_planar, const void *w1, const float *b1, const void *w2, const float *b2,
+                  void *out, int ldo, int batch, int H, int W, rva_stream_t stream_)
+{
+    if (!ctx || !in_planar || !w1 || !b1 || !w2 || !b2 || !out || ldo % 8 || ldo < 64 || batch <= 0 || H < 4 || W < 4)
+        return rva_fail(ctx, RVA_ERR_ARG, "rva_stem2_f16: bad argument");
+    if (W % 8 || ((uintptr_t)in_planar & 15)) return rva_fail(ctx, RVA_ERR_ARG, "rva_stem2_f16: W %% 8 == 0 and a 16-byte aligned input are required");
+    Stem2Args a{(const __half *)in_planar, (const __half *)w1, b1, (const __half *)w2, b2, (__half *)out, ldo, batch, H, W};
+    a.H1 = (H - 1) / 2 + 1; a.W1 = (W - 1) / 2 + 1;
+    a.Ho = (a.H1 - 1) / 2 + 1; a.Wo = (a.W1 - 1) / 2 + 1;
+    a.tiles_x = rva_ceil_div(a.Wo, S2_TW); a.tiles_y = rva_ceil_div(a.Ho, S2_TH);
+    a.total = a.tiles_x * a.tiles_y * batch;
+    constexpr size_t smem = S2_SMEM;
+    RVA_HIP(ctx, rva_func_smem((const void *)k_stem2, smem));
+    if (!ctx->num_cus) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess) ctx->num_cus = prop.multiProcessorCount;
+        if (ctx->num_cus <= 0) ctx->num_cus = 256;
+    }
+    int grid = ctx->num_cus;                               // persistent: one block per CU (159 KB of LDS each)
+    if (grid > a.total) grid = a.total;
+    k_stem2<<<grid, 1024, smem, (hipStream_t)stream_>>>(a);
     RVA_HIP(ctx, hipGetLastError());
     return RVA_OK;
 }

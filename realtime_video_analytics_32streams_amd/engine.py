@@ -235,16 +235,29 @@ class FusedYoloV8:
         sb[:c1] = net.b0.conv.bias.detach().float().cpu()
         sw, sb = sw.to(self.dev), sb.to(self.dev)
         self._keep += [sw, sb]
-        x0 = _View(self._buf(B * h1 * w1, c1), 0, c1)
         L, ctx = self.L, self.ctx
         self._in_ptr = None
-
-        def stem(stream):
-            ctx.check(L.rva_stem_conv_f16(ctx.handle, self._in_ptr, _p(sw), _p(sb),
-                                          x0.ptr, x0.ld, B, H, W, c1, stream), "stem")
-        self._steps.append(stem)
         x1 = _View(self._buf(B * h2 * w2, c2), 0, c2)
-        self._conv(net.b1, x0, x1, h1, w1)
+        import os
+        self.fused_stem = (c1, c2) == (32, 64) and isinstance(net.b1, ConvBnAct) and net.b1.act \
+            and os.environ.get("RVA_NO_STEM2", "0") != "1"
+        if self.fused_stem:
+            # YOLOv8s widths: stem + first downsampling convolution in one launch, the 32-channel half-resolution tensor
+            # (210 MB at batch 32) stays in LDS
+            wp1, bp1, _, _, _, _ = self._conv_params([net.b1.conv])
+
+            def stem2(stream):
+                ctx.check(L.rva_stem2_f16(ctx.handle, self._in_ptr, _p(sw), _p(sb), _p(wp1), _p(bp1),
+                                          x1.ptr, x1.ld, B, H, W, stream), "stem2")
+            self._steps.append(stem2)
+        else:
+            x0 = _View(self._buf(B * h1 * w1, c1), 0, c1)
+
+            def stem(stream):
+                ctx.check(L.rva_stem_conv_f16(ctx.handle, self._in_ptr, _p(sw), _p(sb),
+                                              x0.ptr, x0.ld, B, H, W, c1, stream), "stem")
+            self._steps.append(stem)
+            self._conv(net.b1, x0, x1, h1, w1)
         x2 = _View(self._buf(B * h2 * w2, c2), 0, c2)
         self._c2f(net.b2, x1, x2, h2, w2)
         # concat buffers of the neck: producers write their slice directly

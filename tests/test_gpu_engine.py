@@ -121,6 +121,61 @@ def test_every_conv_variant_agrees(shape):
         assert any(v >= 40 for v in ran), ran          # the 32-channel-step LDS-DMA gather kernel took part
 
 
+def _stem_weights(w1, b1):
+    """[Cout,3,3,3] -> the packed [64][32] fp16 layout of rva_stem_conv_f16 / rva_stem2_f16 (k = 2j + kx | 18 + j, j = c*3 + ky)."""
+    c1 = w1.shape[0]
+    sw = torch.zeros((64, 32), dtype=torch.float16)
+    w0 = w1.float().reshape(c1, 9, 3)
+    sw[:c1, 0:18] = w0[:, :, 0:2].reshape(c1, 18).half()
+    sw[:c1, 18:27] = w0[:, :, 2].half()
+    sb = torch.zeros(64); sb[:c1] = b1
+    return sw.cuda(), sb.cuda()
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 64, 0), (1, 96, 160, 64), (3, 52, 72, 0), (2, 640, 640, 0), (1, 36, 40, 8)])
+def test_fused_stem_and_first_downsampling_conv(shape):
+    """rva_stem2_f16 (3 -> 32 -> 64, both 3x3 s2 + SiLU, one launch) against the fp32 two-convolution reference with the
+    intermediate rounded to fp16, and against the two-launch path (stem kernel -> conv kernel): ragged tiles, image
+    borders inside a tile, an output slice inside a wider buffer."""
+    B, H, W, oe = shape
+    g = torch.Generator().manual_seed(11 + H)
+    x = torch.rand((B, 3, H, W), generator=g).half().cuda()
+    w1 = (torch.randn((32, 3, 3, 3), generator=g) / 27 ** 0.5).half()
+    b1 = torch.randn((32,), generator=g) * 0.2
+    w2 = (torch.randn((64, 32, 3, 3), generator=g) / 288 ** 0.5).half()
+    b2 = torch.randn((64,), generator=g) * 0.2
+    L, ctx = N.lib(), ops.context()
+    sw, sb = _stem_weights(w1, b1)
+    wp = w2.permute(0, 2, 3, 1).reshape(64, 9, 32).contiguous().cuda()
+    bp = b2.clone().cuda()
+    H1, W1 = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    Ho, Wo = (H1 - 1) // 2 + 1, (W1 - 1) // 2 + 1
+    out_full = torch.full((B, Ho, Wo, 64 + oe), 5.0, dtype=torch.float16, device="cuda")
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ctx.check(L.rva_stem2_f16(ctx.handle, C.c_void_p(x.data_ptr()), C.c_void_p(sw.data_ptr()), C.c_void_p(sb.data_ptr()),
+                              C.c_void_p(wp.data_ptr()), C.c_void_p(bp.data_ptr()), C.c_void_p(out_full.data_ptr() + 2 * oe), 64 + oe,
+                              B, H, W, s))
+    torch.cuda.synchronize()
+    mid = F.silu(F.conv2d(x.float(), w1.float().cuda(), b1.cuda(), stride=2, padding=1)).half()
+    want = F.silu(F.conv2d(mid.float(), w2.float().cuda(), b2.cuda(), stride=2, padding=1)).permute(0, 2, 3, 1)
+    got = out_full[..., oe:].float()
+    _assert_conv_close(got, want, None)
+    if oe:
+        assert torch.all(out_full[..., :oe] == 5.0)
+    # the two-launch path on the same operands
+    x0 = torch.empty((B, H1, W1, 32), dtype=torch.float16, device="cuda")
+    ctx.check(L.rva_stem_conv_f16(ctx.handle, C.c_void_p(x.data_ptr()), C.c_void_p(sw.data_ptr()), C.c_void_p(sb.data_ptr()),
+                                  C.c_void_p(x0.data_ptr()), 32, B, H, W, 32, s))
+    two = torch.empty((B, Ho, Wo, 64), dtype=torch.float16, device="cuda")
+    ctx.check(L.rva_conv2d_nhwc_f16(ctx.handle, C.c_void_p(x0.data_ptr()), 32, C.c_void_p(wp.data_ptr()), C.c_void_p(bp.data_ptr()),
+                                    C.c_void_p(two.data_ptr()), 64, None, 0, B, H1, W1, 32, 64, 3, 2, 1, s))
+    torch.cuda.synchronize()
+    # same rounding points; only the fp32 summation order inside the stem's dot product differs
+    diff = (got - two.float()).abs()
+    assert float(diff.max()) <= 2 ** -8, float(diff.max())
+    assert float((diff > 0).float().mean()) < 0.05
+
+
 def test_pool_upsample_head_primitives():
     L, ctx = N.lib(), ops.context()
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
