@@ -15,7 +15,8 @@ def fused(): assert L.rva_stem2_f16(ctx.handle, p(x), p(sw), p(sb), p(wp), p(bp)
 def two():
     assert L.rva_stem_conv_f16(ctx.handle, p(x), p(sw), p(sb), p(x0), 32, B, H, W, 32, s) == 0
     assert L.rva_conv2d_nhwc_f16_v(ctx.handle, p(x0), 32, p(wp), p(bp), p(out), 64, None, 0, B, 320, 320, 32, 64, 3, 2, 1, 43, s) == 0
-for name, fn in (("fused", fused), ("two launches", two), ("fused", fused), ("two launches", two)):
+only = sys.argv[1] if len(sys.argv) > 1 else ""
+for name, fn in [(n_, f_) for n_, f_ in (("fused", fused), ("two launches", two), ("fused", fused), ("two launches", two)) if only in ("", n_)]:
     for _ in range(3): fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
