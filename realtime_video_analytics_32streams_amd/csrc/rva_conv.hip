@@ -1103,7 +1103,12 @@ __device__ __forceinline__ void wait_vm_n(int n)
     case 5: wait_vm<5>(); break;
     case 6: wait_vm<6>(); break;
     case 7: wait_vm<7>(); break;
-    default: wait_vm<8>(); break;
+    case 8: wait_vm<8>(); break;
+    case 9: wait_vm<9>(); break;
+    case 10: wait_vm<10>(); break;
+    case 11: wait_vm<11>(); break;
+    case 12: wait_vm<12>(); break;
+    default: wait_vm<12>(); break;         // more than 12 in flight: waiting down to 12 is stricter than asked, never looser
     }
 }
 
@@ -1724,7 +1729,8 @@ __global__ void __launch_bounds__(512)
         if (t < nsteps) GB_ISSUE();
     const int xr = lane & 7;                                       // BK 64: (row & 7) of every fragment row this lane reads
     for (int s = 0; s < nsteps; ++s) {
-        wait_vm_n(NSLOT == 3 && s + 1 < nsteps ? my_pieces : 0);
+        // steps s+1 .. s+NSLOT-2 may stay in flight (their pieces were issued after step s's)
+        wait_vm_n(NSLOT >= 3 ? min(max(nsteps - 1 - s, 0), NSLOT - 2) * my_pieces : 0);
         __builtin_amdgcn_s_barrier();
         const int sn = s + NSLOT - 1;
         const bool more = sn < nsteps;
@@ -2355,7 +2361,7 @@ __global__ void __launch_bounds__(1024) k_stem2(Stem2Args a)
 
 }  // namespace
 
-#define RVA_CONV_VARIANTS 63
+#define RVA_CONV_VARIANTS 65
 
 extern "C" {
 #ifdef RVA_ROW_STAMPS
@@ -2376,8 +2382,11 @@ int rva_dbg_read_stamps(unsigned long long *host) { return (int)hipMemcpyFromSym
 //   40..42 the same with 32-channel K-steps (Cin % 32 == 0): <256,64> 3-slot, <128,64> 3-slot, <256,64> 2-slot
 //   43..45 patch kernels for Cin = 32 (weights resident, input patch staged once per tile): 3x3 stride 2 with Cout <= 64;
 //          3x3 stride 1 with Cout <= 32, 4- and 8-row tiles
-//   46..49 patch kernels for 3x3 stride 1, Cin = 64, Cout <= 64 (double-buffered 4-row tile, 8-row tile, 4-row tile,
+//   46..51 patch kernels for 3x3 stride 1, Cin = 64, Cout <= 64 (double-buffered 4-row tile, 8-row tile, 4-row tile,
 //          double-buffered 8-row tile, and two forms with two output rows per wave)
+//   52..60 "long run" kernels: a 32-channel chunk's activation run staged once for the three vertical taps (3x3 stride 1)
+//   61..63 patch kernels for Cin = 64 with the output channels in two resident groups of 32
+//   64..65 LDS-DMA gather kernel with 256 x 256 tiles (64 MACs per staged byte; one block per CU): wave tile 64 x 128 / 128 x 64
 int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *weights, const float *bias, void *out,
                           int ldo, const void *residual, int ldr, int batch, int H, int W, int Cin, int Cout, int ksize,
                           int stride, int act, int variant, rva_stream_t stream_);
@@ -2430,6 +2439,21 @@ int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *wei
                                                  stride, act, pick, stream_);
             if (rc == RVA_OK) return rc;
         }
+    }
+    if (variant >= 64) {
+        // LDS-DMA gather kernel with 256-channel output tiles: 43-64 MACs per staged byte against 32 of the 128 x 128 tile.  The CU's
+        // vector-memory path moves 64 B/clk, its MFMAs 4096 MAC/clk: below 64 MAC/B the staging, not the matrix pipe, caps a
+        // 1x1 convolution (a plain GEMM, no tap reuse).  One block per CU.
+        a.CoutPad = cpad;
+        if (ksize == 1 && stride != 1) return rva_fail(ctx, RVA_ERR_ARG, "conv variant %d not applicable here", variant);
+        hipError_t ev;
+        // (measured and dropped: <128,256> tiles, three- and four-slot rings with 32-channel steps -- more bytes in flight per CU
+        //  did not help the memory-latency-bound 1x1 layers, profiles/r02_conv_tuning.txt)
+        if (variant == 64) ev = launch_gbig<256, 256, 4, 2, 2>(a, ksize, s);     // 128 KB ring, wave tile 64 x 128
+        else ev = launch_gbig<256, 256, 2, 4, 2>(a, ksize, s);                   // 128 KB ring, wave tile 128 x 64
+        if (ev == hipSuccess) return RVA_OK;
+        (void)hipGetLastError();
+        return rva_fail(ctx, ev == hipErrorInvalidValue ? RVA_ERR_ARG : RVA_ERR_HIP, "conv variant %d not applicable here", variant);
     }
     if (variant >= 52 && variant <= 60) {
         // "long run" LDS-DMA kernels (3x3 stride 1, Cin % 32 == 0): a chunk's activation run staged once for all three dy
