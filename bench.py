@@ -168,15 +168,14 @@ def main():
     # synthetic weights: shift the class biases so a realistic number of anchors clears the threshold
     with torch.inference_mode():
         sample, _ = ops.preprocess_nv12([src._ring[0] for src in sources[:8]], (640, 640), half=True)
-    # (on the host copy, fp32: the framework's own kernels are the only convolutions this process runs on the GPU, so the
-    # kernel trace of a bench run shows nothing else)
-    cal = copy.deepcopy(net_cpu).eval()
+    # The class logits come from the framework's own plan (logit of the probabilities it emits for 8 sample frames), so the only
+    # convolutions this process runs on the GPU are the framework's kernels and the kernel trace of a bench run shows nothing else.
+    from realtime_video_analytics_32streams_amd.engine import FusedYoloV8
     with torch.inference_mode():
-        shifts = calibrate_detection_density(cal, sample.float().cpu(), args.conf, args.target_dets)
-        for seq in det.net.detect.cls:
-            seq[-1].bias.data[0] += shifts[0]
-            seq[-1].bias.data[1:] += shifts[1]
-    del cal
+        probs = FusedYoloV8(det.net, sample.shape[0], device=dev, autotune=False)(sample.contiguous())[:, 4:, :].float()
+        probs = probs.clamp(2.0 ** -20, 1.0 - 2.0 ** -11)
+        shifts = calibrate_detection_density(det.net, None, args.conf, args.target_dets, class_logits=torch.log(probs / (1.0 - probs)))
+    del probs
     det.invalidate_engine()
     tcfg = TrackerConfig(max_age=30, max_iou_distance=0.5, min_hits=1)
     trk = IouTracker(tcfg, max_streams=S, capacity=1024, device=local)

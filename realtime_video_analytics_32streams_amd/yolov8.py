@@ -312,14 +312,17 @@ def build_detector_net(scale: str = "s", seed: int = 0, weights: Optional[str] =
 
 
 @torch.no_grad()
-def calibrate_detection_density(net: YoloV8, sample: torch.Tensor, conf_thr: float, target_per_image: int = 120,
-                                iters: int = 24) -> Tuple[float, float]:
+def calibrate_detection_density(net: YoloV8, sample: Optional[torch.Tensor], conf_thr: float, target_per_image: int = 120,
+                                iters: int = 24, class_logits: Optional[torch.Tensor] = None) -> Tuple[float, float]:
     """Synthetic-weight helper (bench / smoke only): shift the class-branch biases so that about
     ``target_per_image`` anchors per image clear ``conf_thr`` under the reference's score rule
     (score = p[class0] * max_k p[class k>=1]).  A randomly initialised head
     otherwise emits either nothing or all 8400 anchors, neither of which exercises NMS/tracking
     like a trained detector does.  Returns the two shifts applied (class 0, classes >= 1)."""
-    _, cls = net(sample, raw=True)
+    if class_logits is None:
+        _, cls = net(sample, raw=True)
+    else:
+        cls = class_logits           # [B, nc, A] class logits obtained elsewhere (e.g. logit of the fused plan's probabilities)
     z = cls.float()
     z0, zr = z[:, 0], z[:, 1:].max(1).values
     want = target_per_image * z.shape[0]
