@@ -2108,6 +2108,242 @@ hipError_t launch_patch(S2Args &g, int num_cus, hipStream_t s)
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Patch kernel, two wave sets half a tile period apart (3x3 stride 1, Cin = 64, Cout <= 64; weights resident in LDS).
+//
+// k_conv3_patch<1,64,64,8,1,2> runs its MFMA phase at 95 % of the matrix pipe's time, but per 16 x 32 tile that phase is
+// 9.7 k of 27 k cycles: patch load (5 k), barriers (6 k), SiLU + stage (3 k) and stores (3 k) are all serial around it
+// (tools/patch_stamps.py) -- the weights leave room for one block per CU only, so no second block overlaps them.  Here the
+// block's eight waves are two SETS of four (one wave of each set per SIMD); each set owns a patch buffer and walks its own
+// 8 x 32 tiles, two rows per wave.  Both sets run the same loop
+//     MFMAs of the tile | barrier | issue the next patch, epilogue of the tile, wait for the patch | barrier
+// but set 1 starts one barrier later: whenever a SIMD's set-0 wave is in its MFMA phase the set-1 wave is in its load / epilogue
+// phase and vice versa, so the matrix pipe is fed in both halves of the period and every barrier does double duty (patch free
+// for one set, patch landed for the other).  The epilogue goes from registers to 16-byte stores (v_permlane16_swap between
+// the two 16-pixel halves of a row), there is no LDS left for a stage.
+template <int CIN, int CO>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) k_conv3_patch2(S2Args a)
+{
+    static_assert(CIN == 64 && CO == 64, "64 -> 64 form");
+    constexpr int RPW = 2, SW = 4, TH = SW * RPW, TW = 32, FMW = 2 * RPW, FN = CO / 16, KCH = CIN / 32;
+    constexpr int PH = TH + 2, CW = TW + 2, PROWS = PH * CW;
+    constexpr int RPP = 512 / CIN, LPR = CIN / 8;
+    constexpr int PPIECES = (PROWS + RPP - 1) / RPP, NPP = (PPIECES + SW - 1) / SW;
+    constexpr int WPIECES = 9 * CO / RPP;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __half *wl = (__half *)smem;                           // [9 taps][CO][CIN]   (swizzled rows)
+    __half *patch0 = wl + WPIECES * 512;                   // [2 sets][PPIECES * RPP][CIN]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int set = wv >> 2, ws = wv & 3;                  // wave set, wave within the set
+    const int n = lane & 15, q = lane >> 4;
+    const int lrow = lane / LPR, lp = lane % LPR;
+    const int tiles_img = a.tiles_x * a.tiles_y;
+    auto src_c8 = [&](int row) { return (lp ^ (row & 7)) * 8; };
+    auto lds_off = [&](int row, int c) { return row * 64 + ((c ^ (row & 7)) << 3); };
+
+    // weights: once per block, all eight waves
+#pragma unroll
+    for (int k = 0; k < (WPIECES + 7) / 8; ++k) {
+        const int idx = wv + 8 * k;
+        if (idx < WPIECES) {
+            const int row = idx * RPP + lrow;                       // row = tap * CO + co
+            const int tap = row / CO, co = min(row - tap * CO, a.CoutPad - 1);
+            const __half *src = a.w + (size_t)(co * 9 + tap) * CIN + src_c8(row);
+            __builtin_amdgcn_global_load_lds((glb_vptr)src, (lds_vptr)(wl + idx * 512), 16, 0, 0);
+        }
+    }
+    int pgeo[NPP];                                         // patch position of every LDS row this lane fills: dy << 16 | dx << 8 | source chunk
+#pragma unroll
+    for (int k = 0; k < NPP; ++k) {
+        const int row = (ws + SW * k) * RPP + lrow;
+        const int rc = min(row, PROWS - 1);
+        const int dy = rc / CW;
+        pgeo[k] = (dy << 16) | ((rc - dy * CW) << 8) | src_c8(row);
+    }
+    __half *patch = patch0 + (size_t)set * PPIECES * 512;  // this set's buffer
+    auto issue_patch = [&](int t) {
+        const int b = t / tiles_img, r2 = t - b * tiles_img, ty = r2 / a.tiles_x, tx = r2 - ty * a.tiles_x;
+        const int iy_base = ty * TH - 1, ix_base = tx * TW - 1;
+        const int img = b * a.H;
+#pragma unroll
+        for (int k = 0; k < NPP; ++k) {
+            const int idx = ws + SW * k;
+            if (idx < PPIECES) {
+                const int iy = iy_base + (pgeo[k] >> 16), ix = ix_base + ((pgeo[k] >> 8) & 255);
+                const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                const int px = ok ? (img + iy) * a.W + ix : 0;
+                const __half *src = a.in + (size_t)px * a.ldi + (pgeo[k] & 255);
+                __builtin_amdgcn_global_load_lds((glb_vptr)src, (lds_vptr)(patch + idx * 512), 16, 0, 0);
+            }
+        }
+    };
+    const h8 hz = {0, 0, 0, 0, 0, 0, 0, 0};
+    // Fragment addresses as a few per-lane bases + instruction immediates: every vector instruction beside the MFMAs costs
+    // issue slots the matrix pipe's feeding competes for (an MFMA holds the port 8 of its 16 cycles), and a swizzled offset
+    // computed per fragment was ~30 of them per 16 MFMAs.  B: the patch row of pixel n for wave-row r in 0 .. RPW+1 and
+    // dx in 0..2 (the +16-pixel half is +1024 halfs, same swizzle; the second 32-channel half is the offset ^ 32);
+    // A: row tap * CO + 16 i + n has (row & 7) = n & 7, so tap and i are immediates.
+    int boff[RPW + 2][3];
+#pragma unroll
+    for (int r = 0; r < RPW + 2; ++r)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) boff[r][dx] = lds_off((ws * RPW + r) * CW + dx + n, q);
+    const int aoff = lds_off(n, q);
+    float *bias_l = reinterpret_cast<float *>(patch0 + (size_t)2 * PPIECES * 512);      // [CO]: registers are scarce, a global read per tile would expose its latency
+    if (tid < CO) bias_l[tid] = a.bias[min(tid, a.CoutPad - 1)];
+    // tiles of this block: t = blockIdx.x + j * gridDim.x, j = 0, 1, ...; set s takes j = s, s + 2, ...
+    const int nblk_tiles = (int)blockIdx.x < a.total ? (a.total - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+    const int nmine = (nblk_tiles - set + 1) / 2;          // tiles of this set
+    const int niter = (nblk_tiles + 1) / 2;                // iterations both sets run (set 0 has the larger share)
+#ifdef RVA_ROW_STAMPS
+    const int st_stride = gridDim.x / 4;
+    const bool st_on = (tid == 0 || tid == 256) && st_stride > 0 && blockIdx.x % st_stride == 0 && blockIdx.x / st_stride < 4;
+    const int st_slot = st_on ? (blockIdx.x / st_stride) * 2 + (tid >> 8) : 0;
+    int st_n = 0;
+#endif
+    if (nmine > 0) issue_patch(blockIdx.x + set * gridDim.x);
+    wait_vm<0>();
+    __builtin_amdgcn_s_barrier();                          // weights and both first patches are in LDS
+    if (set == 1) __builtin_amdgcn_s_barrier();            // half a period behind set 0
+    for (int it = 0; it < niter; ++it) {
+        const bool live = it < nmine;
+        const int t = blockIdx.x + (2 * it + set) * gridDim.x;
+        const int b = t / tiles_img, r2 = t - b * tiles_img, ty = r2 / a.tiles_x, tx = r2 - ty * a.tiles_x;
+        STAMP(0);
+        f4 acc[FN][FMW];
+        if (live) {
+            int vm[FMW];
+#pragma unroll
+            for (int j = 0; j < FMW; ++j) {
+                const int oy = ty * TH + ws * RPW + (j >> 1), ox = tx * TW + 16 * (j & 1) + n;
+                int m = 0;
+                if (oy < a.Ho && ox < a.Wo) {
+                    const int hv = (ox >= 1 ? 1 : 0) | 2 | (ox <= a.W - 2 ? 4 : 0);
+                    m = (oy >= 1 ? hv : 0) | (hv << 3) | (oy <= a.H - 2 ? hv << 6 : 0);
+                }
+                vm[j] = m;
+            }
+            // taps that some lane of this wave has to zero (wave-uniform): most tiles need none, the selects are skipped
+            int vall = 0x1ff;
+#pragma unroll
+            for (int j = 0; j < FMW; ++j) vall &= vm[j];
+            int need = 0;
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp)
+                if (__builtin_amdgcn_ballot_w64(!((vall >> tp) & 1)) != 0) need |= 1 << tp;
+            need = __builtin_amdgcn_readfirstlane(need);
+#pragma unroll
+            for (int i = 0; i < FN; ++i)
+#pragma unroll
+                for (int j = 0; j < FMW; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+            // group g = (tap, 32-channel half): FMW B + FN A fragments, FMW x FN MFMAs.  This wave is the only one of its SIMD in
+            // the MFMA phase: the next group's fragments are read while this group's MFMAs run, and the padding taps are
+            // zeroed where a fragment is consumed (a select behind the load would wait for it at once).
+            constexpr int NG = 9 * KCH;
+            h8 bfa[FMW], afa[FN], bfb[FMW], afb[FN];
+#define P2_LOAD(BF, AF, G)                                                                                          \
+            do {                                                                                                    \
+                constexpr int tp_ = (G) / KCH, ks_ = (G) % KCH, dy_ = tp_ / 3, dx_ = tp_ % 3;                       \
+                _Pragma("unroll") for (int j = 0; j < FMW; ++j)                                                     \
+                    BF[j] = *reinterpret_cast<const h8 *>(patch + (boff[dy_ + (j >> 1)][dx_] ^ (ks_ * 32)) + (j & 1) * 1024); \
+                _Pragma("unroll") for (int i = 0; i < FN; ++i)                                                      \
+                    AF[i] = *reinterpret_cast<const h8 *>(wl + (aoff ^ (ks_ * 32)) + (tp_ * CO + 16 * i) * 64);     \
+            } while (0)
+#define P2_MFMA(BF, AF, G)                                                                                          \
+            do {                                                                                                    \
+                constexpr int tp_ = (G) / KCH;                                                                      \
+                if ((need >> tp_) & 1) {                                                                            \
+                    _Pragma("unroll") for (int j = 0; j < FMW; ++j)                                                 \
+                        if (!((vm[j] >> tp_) & 1)) BF[j] = hz;                                                      \
+                }                                                                                                   \
+                _Pragma("unroll") for (int i = 0; i < FN; ++i)                                                      \
+                    _Pragma("unroll") for (int j = 0; j < FMW; ++j)                                                 \
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(AF[i], BF[j], acc[i][j], 0, 0, 0);       \
+            } while (0)
+            static_assert(NG == 18, "the group loop below is written out for nine taps x two channel halves");
+#define P2_PAIR(G)   P2_LOAD(bfb, afb, (G) + 1); P2_MFMA(bfa, afa, (G)); P2_LOAD(bfa, afa, (G) + 2); P2_MFMA(bfb, afb, (G) + 1)
+            P2_LOAD(bfa, afa, 0);
+            P2_PAIR(0); P2_PAIR(2); P2_PAIR(4); P2_PAIR(6); P2_PAIR(8); P2_PAIR(10); P2_PAIR(12); P2_PAIR(14);
+            P2_LOAD(bfb, afb, 17); P2_MFMA(bfa, afa, 16); P2_MFMA(bfb, afb, 17);
+#undef P2_PAIR
+#undef P2_LOAD
+#undef P2_MFMA
+        }
+        STAMP(1);
+        __builtin_amdgcn_s_barrier();        // this set has left its patch (the other set: its next patch has landed)
+        STAMP(2);
+        if (it + 1 < nmine) issue_patch(t + 2 * gridDim.x);
+        STAMP(3);
+        if (live) {
+            // bias + SiLU in registers, one v_permlane16_swap per packed dword between the two 16-pixel halves of a row: lane
+            // (n, q) ends up with eight consecutive channels of pixel n of half (q & 1), channels 16 i + 8 (q >> 1) ..
+            const int qh = q & 1, qc = q >> 1;
+            const int ox = tx * TW + 16 * qh + n;
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const int oy = ty * TH + ws * RPW + r;
+                const bool pv = oy < a.Ho && ox < a.Wo;
+                const size_t m = (size_t)(b * a.Ho + oy) * a.Wo + ox;
+#pragma unroll
+                for (int i = 0; i < FN; ++i) {
+                    const float4 bv = *reinterpret_cast<const float4 *>(bias_l + 16 * i + q * 4);
+                    uint32_t w2[2][2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const f4 c = acc[i][2 * r + h];
+                        float v0 = c[0] + bv.x, v1 = c[1] + bv.y, v2 = c[2] + bv.z, v3 = c[3] + bv.w;
+                        if (a.act) { v0 = silu_f(v0); v1 = silu_f(v1); v2 = silu_f(v2); v3 = silu_f(v3); }
+                        __half2 lo = __floats2half2_rn(v0, v1), hi = __floats2half2_rn(v2, v3);
+                        w2[h][0] = *reinterpret_cast<uint32_t *>(&lo);
+                        w2[h][1] = *reinterpret_cast<uint32_t *>(&hi);
+                    }
+                    const auto s0 = __builtin_amdgcn_permlane16_swap(w2[0][0], w2[1][0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane16_swap(w2[0][1], w2[1][1], false, false);
+                    uint4 v = {s0[0], s1[0], s0[1], s1[1]};
+                    const int co = 16 * i + 8 * qc;
+                    if (pv && co < a.Cout) {
+                        if (a.res) {
+                            const uint4 rr = *reinterpret_cast<const uint4 *>(a.res + m * a.ldr + co);
+                            __half2 *vh = reinterpret_cast<__half2 *>(&v);
+                            const __half2 *rh = reinterpret_cast<const __half2 *>(&rr);
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const float2 x = __half22float2(vh[u]), y = __half22float2(rh[u]);
+                                vh[u] = __floats2half2_rn(x.x + y.x, x.y + y.y);
+                            }
+                        }
+                        *reinterpret_cast<uint4 *>(a.out + m * a.ldo + co) = v;
+                    }
+                }
+            }
+        }
+        STAMP(4);
+        wait_vm<0>();                        // the next patch (issued above) has landed; the stores have left too
+        STAMP(5);
+        __builtin_amdgcn_s_barrier();        // ... for every wave of this set (the other set: it has left ITS patch)
+    }
+    if (set == 0) __builtin_amdgcn_s_barrier();            // the barrier set 1 took ahead of its loop
+}
+
+template <int CIN, int CO>
+hipError_t launch_patch2(S2Args &g, int num_cus, hipStream_t s)
+{
+    constexpr int RPP = 512 / CIN, TH = 8;
+    constexpr int PROWS = (TH + 2) * 34;
+    constexpr size_t smem = (size_t)(9 * CO / RPP + 2 * ((PROWS + RPP - 1) / RPP)) * 1024 + CO * 4;
+    static_assert(smem <= 160 * 1024, "LDS budget");
+    if (g.Cout > CO || g.Cout % 8) return hipErrorInvalidValue;
+    if (hipError_t e = rva_func_smem((const void *)k_conv3_patch2<CIN, CO>, smem); e != hipSuccess) return e;
+    g.tiles_x = rva_ceil_div(g.Wo, 32); g.tiles_y = rva_ceil_div(g.Ho, TH);
+    g.total = g.tiles_x * g.tiles_y * g.B;
+    g.n_tiles = 1;
+    int grid = num_cus;
+    if (grid > g.total) grid = g.total;
+    k_conv3_patch2<CIN, CO><<<grid, 512, smem, s>>>(g);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Stem + first downsampling convolution in ONE launch, for the YOLOv8s widths (3 -> 32 -> 64, both 3x3 stride 2, SiLU).
 //
 // As two launches the pair moves 78 MB in, 210 MB out (stem), 210 MB in again and 105 MB out: 600 MB per 32-frame batch,
@@ -2361,7 +2597,7 @@ __global__ void __launch_bounds__(1024) k_stem2(Stem2Args a)
 
 }  // namespace
 
-#define RVA_CONV_VARIANTS 65
+#define RVA_CONV_VARIANTS 66
 
 extern "C" {
 #ifdef RVA_ROW_STAMPS
@@ -2387,6 +2623,7 @@ int rva_dbg_read_stamps(unsigned long long *host) { return (int)hipMemcpyFromSym
 //   52..60 "long run" kernels: a 32-channel chunk's activation run staged once for the three vertical taps (3x3 stride 1)
 //   61..63 patch kernels for Cin = 64 with the output channels in two resident groups of 32
 //   64..65 LDS-DMA gather kernel with 256 x 256 tiles (64 MACs per staged byte; one block per CU): wave tile 64 x 128 / 128 x 64
+//   66     patch kernel with two wave sets half a tile period apart (3x3 stride 1, Cin = 64, Cout <= 64)
 int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *weights, const float *bias, void *out,
                           int ldo, const void *residual, int ldr, int batch, int H, int W, int Cin, int Cout, int ksize,
                           int stride, int act, int variant, rva_stream_t stream_);
@@ -2439,6 +2676,15 @@ int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *wei
                                                  stride, act, pick, stream_);
             if (rc == RVA_OK) return rc;
         }
+    }
+    if (variant >= 66) {
+        // patch kernel with two wave sets half a tile period apart (3x3 stride 1, Cin = 64, Cout <= 64)
+        hipError_t ev = hipErrorInvalidValue;
+        S2Args g{a.in, ldi, a.w, bias, a.out, ldo, a.res, ldr, batch, H, W, a.Ho, a.Wo, Cout, cpad, act, 0, 0, 0};
+        if (ksize == 3 && stride == 1 && Cin == 64 && Cout <= 64) ev = launch_patch2<64, 64>(g, num_cus, s);
+        if (ev == hipSuccess) return RVA_OK;
+        (void)hipGetLastError();
+        return rva_fail(ctx, ev == hipErrorInvalidValue ? RVA_ERR_ARG : RVA_ERR_HIP, "conv variant %d not applicable here", variant);
     }
     if (variant >= 64) {
         // LDS-DMA gather kernel with 256-channel output tiles: 43-64 MACs per staged byte against 32 of the 128 x 128 tile.  The CU's
