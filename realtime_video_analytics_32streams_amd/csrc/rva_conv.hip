@@ -1396,7 +1396,7 @@ struct RunArgs {
 };
 
 template <int BM, int BN, int WGM, int WGN>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BN <= 64 ? 4 : 2))) k_conv3_run(RunArgs a)
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BN <= 64 && BM <= 320 ? 4 : 2))) k_conv3_run(RunArgs a)
 {
     static_assert(WGM * WGN == 8, "eight waves");
     constexpr int TM = BM / WGM, TN = BN / WGN, FM = TM / 16, FN = TN / 16;
@@ -1464,6 +1464,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BN <= 
 #pragma unroll
     for (int k = 0; k < NPW; ++k)
         if (wv + 8 * k < WPIECES) lds_dma16(woff[k], a.w, lds_w + (unsigned)(wv + 8 * k) * 1024u);
+    const int wlane = swz32(wn * TN + (lane & 15), lane >> 4);      // this lane's weight row of fragment 0, tap 0
 
     int cc = 0, dy = 0;
     for (int s = 0; s < nsteps; ++s) {
@@ -1496,24 +1497,39 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BN <= 
         if (early) RUN_ISSUE();
         const __half *ab = act0 + (size_t)(cc & 1) * apieces * 512;
         const __half *wb = wt0 + (size_t)(s & 1) * WPIECES * 512;
+        // Fragment addresses = one swizzled per-lane base per horizontal tap + instruction immediates (16 rows further the
+        // rotation of swz32 is the same; weight rows are the lane's base + a multiple of 16 rows): the PMC pass showed 4.4 vector
+        // instructions per MFMA in this kernel, and every one of them competes with the MFMAs for the SIMD's issue port.
         const int arow = wm * TM + (lane & 15) + dy * a.W, ch = lane >> 4;
+        const int abase[3] = {swz32(arow, ch), swz32(arow + 1, ch), swz32(arow + 2, ch)};
         const int vsh = dy * 3;
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-            h8 bf[FM];
-#pragma unroll
-            for (int j = 0; j < FM; ++j) {
-                bf[j] = *reinterpret_cast<const h8 *>(ab + swz32(arow + j * 16 + dx, ch));
-                if (!((vm[j] >> (vsh + dx)) & 1)) bf[j] = hz;
-            }
-#pragma unroll
-            for (int i = 0; i < FN; ++i) {
-                const h8 a1 = *reinterpret_cast<const h8 *>(wb + swz32(dx * BN + wn * TN + i * 16 + (lane & 15), ch));
-#pragma unroll
-                for (int j = 0; j < FM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bf[j], acc[i][j], 0, 0, 0);
-            }
-            if (dx == 0 && !early) RUN_ISSUE();
-        }
+        // the fragments of the next horizontal tap are read while the MFMAs of this one run (two register sets); the padding
+        // taps are zeroed where a fragment is consumed, a select right behind the load would wait for it at once
+        h8 bfx[2][FM], afx[2][FN];
+#define RUN_LOAD(S, DX)                                                                                          \
+        do {                                                                                                     \
+            _Pragma("unroll") for (int j = 0; j < FM; ++j)                                                       \
+                bfx[S][j] = *reinterpret_cast<const h8 *>(ab + abase[DX] + j * (16 * 32));                       \
+            _Pragma("unroll") for (int i = 0; i < FN; ++i)                                                       \
+                afx[S][i] = *reinterpret_cast<const h8 *>(wb + wlane + ((DX) * BN + i * 16) * 32);               \
+        } while (0)
+#define RUN_MFMA(S, DX)                                                                                          \
+        do {                                                                                                     \
+            _Pragma("unroll") for (int j = 0; j < FM; ++j)                                                       \
+                if (!((vm[j] >> (vsh + (DX))) & 1)) bfx[S][j] = hz;                                              \
+            _Pragma("unroll") for (int i = 0; i < FN; ++i)                                                       \
+                _Pragma("unroll") for (int j = 0; j < FM; ++j)                                                   \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afx[S][i], bfx[S][j], acc[i][j], 0, 0, 0); \
+        } while (0)
+        RUN_LOAD(0, 0);
+        RUN_LOAD(1, 1);
+        RUN_MFMA(0, 0);
+        if (!early) RUN_ISSUE();
+        RUN_LOAD(0, 2);
+        RUN_MFMA(1, 1);
+        RUN_MFMA(0, 2);
+#undef RUN_LOAD
+#undef RUN_MFMA
 #undef RUN_ISSUE
         cc = ncc; dy = ndy;
     }
