@@ -2129,18 +2129,21 @@ hipError_t launch_patch(S2Args &g, int num_cus, hipStream_t s)
 // k_conv3_patch<1,64,64,8,1,2> runs its MFMA phase at 95 % of the matrix pipe's time, but per 16 x 32 tile that phase is
 // 9.7 k of 27 k cycles: patch load (5 k), barriers (6 k), SiLU + stage (3 k) and stores (3 k) are all serial around it
 // (tools/patch_stamps.py) -- the weights leave room for one block per CU only, so no second block overlaps them.  Here the
-// block's eight waves are two SETS of four (one wave of each set per SIMD); each set owns a patch buffer and walks its own
-// 8 x 32 tiles, two rows per wave.  Both sets run the same loop
+// block's waves are two SETS (SW waves each, RPW output rows per wave, 8 x 32 tiles); each set owns a patch buffer and walks
+// its own tiles.  Both sets run the same loop
 //     MFMAs of the tile | barrier | issue the next patch, epilogue of the tile, wait for the patch | barrier
-// but set 1 starts one barrier later: whenever a SIMD's set-0 wave is in its MFMA phase the set-1 wave is in its load / epilogue
-// phase and vice versa, so the matrix pipe is fed in both halves of the period and every barrier does double duty (patch free
-// for one set, patch landed for the other).  The epilogue goes from registers to 16-byte stores (v_permlane16_swap between
-// the two 16-pixel halves of a row), there is no LDS left for a stage.
-template <int CIN, int CO>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) k_conv3_patch2(S2Args a)
+// but set 1 starts one barrier later: whenever a SIMD's set-0 waves are in their MFMA phase the set-1 waves are in their load /
+// epilogue phase and vice versa, so the matrix pipe is fed in both halves of the period and every barrier does double duty
+// (patch free for one set, patch landed for the other).  The epilogue goes from registers to 16-byte stores
+// (v_permlane16_swap between the two 16-pixel halves of a row), there is no LDS left for a stage.  Instantiated as 2 x 8 waves
+// of 128 registers, one row per wave: an MFMA phase fed from LDS needs TWO waves per SIMD to run near the pipe's rate (one
+// reaches ~55 % however its loads are software-pipelined: the 2 x 4 waves x two rows form measured that).
+template <int CIN, int CO, int SW, int RPW>
+__global__ void __launch_bounds__(2 * SW * 64) __attribute__((amdgpu_waves_per_eu(SW / 2, SW / 2))) k_conv3_patch2(S2Args a)
 {
     static_assert(CIN == 64 && CO == 64, "64 -> 64 form");
-    constexpr int RPW = 2, SW = 4, TH = SW * RPW, TW = 32, FMW = 2 * RPW, FN = CO / 16, KCH = CIN / 32;
+    static_assert(SW * RPW == 8 && (SW == 4 || SW == 8), "8-row tiles: four waves x two rows or eight waves x one row per set");
+    constexpr int NWAVES = 2 * SW, TH = SW * RPW, TW = 32, FMW = 2 * RPW, FN = CO / 16, KCH = CIN / 32;
     constexpr int PH = TH + 2, CW = TW + 2, PROWS = PH * CW;
     constexpr int RPP = 512 / CIN, LPR = CIN / 8;
     constexpr int PPIECES = (PROWS + RPP - 1) / RPP, NPP = (PPIECES + SW - 1) / SW;
@@ -2150,7 +2153,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     __half *patch0 = wl + WPIECES * 512;                   // [2 sets][PPIECES * RPP][CIN]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int set = wv >> 2, ws = wv & 3;                  // wave set, wave within the set
+    const int set = wv / SW, ws = wv % SW;                 // wave set, wave within the set
     const int n = lane & 15, q = lane >> 4;
     const int lrow = lane / LPR, lp = lane % LPR;
     const int tiles_img = a.tiles_x * a.tiles_y;
@@ -2159,8 +2162,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 
     // weights: once per block, all eight waves
 #pragma unroll
-    for (int k = 0; k < (WPIECES + 7) / 8; ++k) {
-        const int idx = wv + 8 * k;
+    for (int k = 0; k < (WPIECES + NWAVES - 1) / NWAVES; ++k) {
+        const int idx = wv + NWAVES * k;
         if (idx < WPIECES) {
             const int row = idx * RPP + lrow;                       // row = tap * CO + co
             const int tap = row / CO, co = min(row - tap * CO, a.CoutPad - 1);
@@ -2168,28 +2171,34 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             __builtin_amdgcn_global_load_lds((glb_vptr)src, (lds_vptr)(wl + idx * 512), 16, 0, 0);
         }
     }
-    int pgeo[NPP];                                         // patch position of every LDS row this lane fills: dy << 16 | dx << 8 | source chunk
+    // Patch pieces through lds_dma16: a wave-uniform 64-bit base (the patch's top-left pixel) + one 32-bit byte offset per lane,
+    // tile-invariant and computed once; per tile only the validity of the lane's pixel is tested (lanes outside the image
+    // re-read the tile's first output pixel, their taps are masked in the B fragments).  Through the builtin a piece cost
+    // ~25 vector instructions of address arithmetic, issued beside the other set's MFMA phase.
+    unsigned poff[NPP];
+    int pgeo[NPP];                                         // dy << 8 | dx of the lane's patch pixel
+    const unsigned ldi2 = (unsigned)a.ldi * 2u;
 #pragma unroll
     for (int k = 0; k < NPP; ++k) {
         const int row = (ws + SW * k) * RPP + lrow;
         const int rc = min(row, PROWS - 1);
-        const int dy = rc / CW;
-        pgeo[k] = (dy << 16) | ((rc - dy * CW) << 8) | src_c8(row);
+        const int dy = rc / CW, dx = rc - dy * CW;
+        pgeo[k] = (dy << 8) | dx;
+        poff[k] = (unsigned)(dy * a.W + dx) * ldi2 + (unsigned)src_c8(row) * 2u;
     }
     __half *patch = patch0 + (size_t)set * PPIECES * 512;  // this set's buffer
+    const unsigned lds_patch = lds_addr(patch);
     auto issue_patch = [&](int t) {
         const int b = t / tiles_img, r2 = t - b * tiles_img, ty = r2 / a.tiles_x, tx = r2 - ty * a.tiles_x;
         const int iy_base = ty * TH - 1, ix_base = tx * TW - 1;
-        const int img = b * a.H;
+        const char *base = (const char *)a.in + ((long long)(b * a.H + iy_base) * a.W + ix_base) * (long long)ldi2;
+        const unsigned centre = (unsigned)(a.W + 1) * ldi2;
 #pragma unroll
         for (int k = 0; k < NPP; ++k) {
             const int idx = ws + SW * k;
             if (idx < PPIECES) {
-                const int iy = iy_base + (pgeo[k] >> 16), ix = ix_base + ((pgeo[k] >> 8) & 255);
-                const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-                const int px = ok ? (img + iy) * a.W + ix : 0;
-                const __half *src = a.in + (size_t)px * a.ldi + (pgeo[k] & 255);
-                __builtin_amdgcn_global_load_lds((glb_vptr)src, (lds_vptr)(patch + idx * 512), 16, 0, 0);
+                const bool ok = (unsigned)(iy_base + (pgeo[k] >> 8)) < (unsigned)a.H && (unsigned)(ix_base + (pgeo[k] & 255)) < (unsigned)a.W;
+                lds_dma16(ok ? poff[k] : centre, base, lds_patch + (unsigned)idx * 1024u);
             }
         }
     };
@@ -2213,8 +2222,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     const int niter = (nblk_tiles + 1) / 2;                // iterations both sets run (set 0 has the larger share)
 #ifdef RVA_ROW_STAMPS
     const int st_stride = gridDim.x / 4;
-    const bool st_on = (tid == 0 || tid == 256) && st_stride > 0 && blockIdx.x % st_stride == 0 && blockIdx.x / st_stride < 4;
-    const int st_slot = st_on ? (blockIdx.x / st_stride) * 2 + (tid >> 8) : 0;
+    const bool st_on = (tid == 0 || tid == SW * 64) && st_stride > 0 && blockIdx.x % st_stride == 0 && blockIdx.x / st_stride < 4;
+    const int st_slot = st_on ? (blockIdx.x / st_stride) * 2 + (tid >= SW * 64 ? 1 : 0) : 0;
     int st_n = 0;
 #endif
     if (nmine > 0) issue_patch(blockIdx.x + set * gridDim.x);
@@ -2278,9 +2287,19 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             } while (0)
             static_assert(NG == 18, "the group loop below is written out for nine taps x two channel halves");
 #define P2_PAIR(G)   P2_LOAD(bfb, afb, (G) + 1); P2_MFMA(bfa, afa, (G)); P2_LOAD(bfa, afa, (G) + 2); P2_MFMA(bfb, afb, (G) + 1)
-            P2_LOAD(bfa, afa, 0);
-            P2_PAIR(0); P2_PAIR(2); P2_PAIR(4); P2_PAIR(6); P2_PAIR(8); P2_PAIR(10); P2_PAIR(12); P2_PAIR(14);
-            P2_LOAD(bfb, afb, 17); P2_MFMA(bfa, afa, 16); P2_MFMA(bfb, afb, 17);
+#define P2_ONE(G)    P2_LOAD(bfa, afa, (G)); P2_MFMA(bfa, afa, (G))
+            if constexpr (RPW == 2) {
+                // one MFMA wave of this set per SIMD: the next group's fragments are read under this group's MFMAs
+                P2_LOAD(bfa, afa, 0);
+                P2_PAIR(0); P2_PAIR(2); P2_PAIR(4); P2_PAIR(6); P2_PAIR(8); P2_PAIR(10); P2_PAIR(12); P2_PAIR(14);
+                P2_LOAD(bfb, afb, 17); P2_MFMA(bfa, afa, 16); P2_MFMA(bfb, afb, 17);
+            } else {
+                // two MFMA waves of this set per SIMD cover each other's fragment latency; 128 registers per wave
+                P2_ONE(0); P2_ONE(1); P2_ONE(2); P2_ONE(3); P2_ONE(4); P2_ONE(5); P2_ONE(6); P2_ONE(7); P2_ONE(8);
+                P2_ONE(9); P2_ONE(10); P2_ONE(11); P2_ONE(12); P2_ONE(13); P2_ONE(14); P2_ONE(15); P2_ONE(16); P2_ONE(17);
+                (void)bfb; (void)afb;
+            }
+#undef P2_ONE
 #undef P2_PAIR
 #undef P2_LOAD
 #undef P2_MFMA
@@ -2341,7 +2360,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     if (set == 0) __builtin_amdgcn_s_barrier();            // the barrier set 1 took ahead of its loop
 }
 
-template <int CIN, int CO>
+template <int CIN, int CO, int SW, int RPW>
 hipError_t launch_patch2(S2Args &g, int num_cus, hipStream_t s)
 {
     constexpr int RPP = 512 / CIN, TH = 8;
@@ -2349,13 +2368,13 @@ hipError_t launch_patch2(S2Args &g, int num_cus, hipStream_t s)
     constexpr size_t smem = (size_t)(9 * CO / RPP + 2 * ((PROWS + RPP - 1) / RPP)) * 1024 + CO * 4;
     static_assert(smem <= 160 * 1024, "LDS budget");
     if (g.Cout > CO || g.Cout % 8) return hipErrorInvalidValue;
-    if (hipError_t e = rva_func_smem((const void *)k_conv3_patch2<CIN, CO>, smem); e != hipSuccess) return e;
+    if (hipError_t e = rva_func_smem((const void *)k_conv3_patch2<CIN, CO, SW, RPW>, smem); e != hipSuccess) return e;
     g.tiles_x = rva_ceil_div(g.Wo, 32); g.tiles_y = rva_ceil_div(g.Ho, TH);
     g.total = g.tiles_x * g.tiles_y * g.B;
     g.n_tiles = 1;
     int grid = num_cus;
     if (grid > g.total) grid = g.total;
-    k_conv3_patch2<CIN, CO><<<grid, 512, smem, s>>>(g);
+    k_conv3_patch2<CIN, CO, SW, RPW><<<grid, 2 * SW * 64, smem, s>>>(g);
     return hipGetLastError();
 }
 
@@ -2639,7 +2658,7 @@ int rva_dbg_read_stamps(unsigned long long *host) { return (int)hipMemcpyFromSym
 //   52..60 "long run" kernels: a 32-channel chunk's activation run staged once for the three vertical taps (3x3 stride 1)
 //   61..63 patch kernels for Cin = 64 with the output channels in two resident groups of 32
 //   64..65 LDS-DMA gather kernel with 256 x 256 tiles (64 MACs per staged byte; one block per CU): wave tile 64 x 128 / 128 x 64
-//   66     patch kernel with two wave sets half a tile period apart (3x3 stride 1, Cin = 64, Cout <= 64)
+//   66     patch kernel with two wave sets half a tile period apart (3x3 stride 1, Cin = 64, Cout <= 64): 2 x 8 waves, one output row per wave
 int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *weights, const float *bias, void *out,
                           int ldo, const void *residual, int ldr, int batch, int H, int W, int Cin, int Cout, int ksize,
                           int stride, int act, int variant, rva_stream_t stream_);
@@ -2697,7 +2716,9 @@ int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *wei
         // patch kernel with two wave sets half a tile period apart (3x3 stride 1, Cin = 64, Cout <= 64)
         hipError_t ev = hipErrorInvalidValue;
         S2Args g{a.in, ldi, a.w, bias, a.out, ldo, a.res, ldr, batch, H, W, a.Ho, a.Wo, Cout, cpad, act, 0, 0, 0};
-        if (ksize == 3 && stride == 1 && Cin == 64 && Cout <= 64) ev = launch_patch2<64, 64>(g, num_cus, s);
+        // sixteen waves: two sets of eight, one output row per wave -- two MFMA waves per SIMD in every phase.  (The 2 x 4 waves x
+        // two rows form, one 256-register MFMA wave per SIMD, measured 27.0 us against 25.6 us at 80 x 80 and was dropped.)
+        if (ksize == 3 && stride == 1 && Cin == 64 && Cout <= 64) ev = launch_patch2<64, 64, 8, 1>(g, num_cus, s);
         if (ev == hipSuccess) return RVA_OK;
         (void)hipGetLastError();
         return rva_fail(ctx, ev == hipErrorInvalidValue ? RVA_ERR_ARG : RVA_ERR_HIP, "conv variant %d not applicable here", variant);

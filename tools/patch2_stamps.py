@@ -10,7 +10,7 @@ if "--build-only" in sys.argv or not DBG.exists():
     if "--build-only" in sys.argv:
         sys.exit(0)
 import numpy as np, torch
-H = int(sys.argv[1]); cin = 64; B = 32
+H = int(sys.argv[1]); cin = 64; B = 32; VAR = int(sys.argv[2]) if len(sys.argv) > 2 else 66
 L = C.CDLL(str(DBG)); ctx = C.c_void_p(); assert L.rva_create(0, C.byref(ctx)) == 0
 x = torch.randn((B, H, H, cin), device="cuda").half()
 out = torch.empty((B, H, H, cin), device="cuda", dtype=torch.float16)
@@ -19,7 +19,7 @@ b = torch.zeros(64, device="cuda")
 s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 L.rva_conv2d_nhwc_f16_v.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int] + [C.c_int] * 8 + [C.c_int, C.c_void_p]
 for _ in range(3):
-    assert L.rva_conv2d_nhwc_f16_v(ctx, x.data_ptr(), cin, w.data_ptr(), b.data_ptr(), out.data_ptr(), cin, None, 0, B, H, H, cin, cin, 3, 1, 1, 66, s) == 0
+    assert L.rva_conv2d_nhwc_f16_v(ctx, x.data_ptr(), cin, w.data_ptr(), b.data_ptr(), out.data_ptr(), cin, None, 0, B, H, H, cin, cin, 3, 1, 1, VAR, s) == 0
 torch.cuda.synchronize()
 host = np.zeros((8, 256), dtype=np.uint64)
 assert L.rva_dbg_read_stamps(host.ctypes.data_as(C.c_void_p)) == 0
