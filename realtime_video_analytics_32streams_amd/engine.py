@@ -365,6 +365,8 @@ class FusedYoloV8:
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         self.tuning = []
         self._n_variants = int(N.lib().rva_conv_num_variants())
+        import os
+        skip = {int(v) for v in os.environ.get("RVA_SKIP_VARIANTS", "").replace(",", " ").split()}      # tuning aid: same-box A/B of kernel families
         cache = {}
         for launch, state, desc in self._tunable:
             if desc in cache:
@@ -372,7 +374,7 @@ class FusedYoloV8:
                 continue
             best = (0, float("inf"))
             for variant in range(1, self._n_variants + 1):
-                if launch(stream, variant) != N.RVA_OK:
+                if variant in skip or launch(stream, variant) != N.RVA_OK:
                     continue
                 torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
