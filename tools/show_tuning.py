@@ -35,6 +35,8 @@ for d, n in seen.items():
     rows.append((gap, f"{d:24s} x{n} {names[v]:14s} {us:7.1f} us  hbm {t_hbm:6.1f}  mfma {t_mfma:6.1f}  x{us/roof:4.1f} of roof  gap*n {gap:7.1f} us"))
 for _, r in sorted(rows, reverse=True):
     print(r)
+for r in getattr(eng, "refined", None) or []:
+    print("in-plan refinement:", r[0], names.get(r[1], r[1]), "->", names.get(r[2], r[2]), "forward", r[3], "->", r[4], "us")
 print("sum of gaps to the per-layer roofline:", round(gap_tot, 1), "us")
 print("sum conv us per forward:", round(tot, 1))
 x = torch.rand((B, 3, 640, 640), device="cuda").half()
