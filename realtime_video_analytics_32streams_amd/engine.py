@@ -391,12 +391,14 @@ class FusedYoloV8:
                     best = (variant, us)
             state["variant"] = best[0]
             cache[desc] = best
-            self._candidates[desc] = sorted(timed)[:5]
+            self._candidates[desc] = sorted(timed)[:int(os.environ.get('RVA_TUNE_TOP', '5'))]
             self.tuning.append((desc, best[0], round(best[1], 1)))
         if os.environ.get("RVA_TUNE_IN_PLAN", "1") == "1":
             self._refine_in_plan()
 
     def _refine_in_plan(self, reps: int = 12, within: float = 1.25) -> None:
+        import os
+        within = float(os.environ.get('RVA_TUNE_WITHIN', within))
         """Second pass of the kernel selection, on the real objective: a layer's launch time in isolation is not its cost inside
         the plan -- the detect branches run on side streams beside the neck, and a kernel that wants every CU for itself (one
         128-KB workgroup per CU) shares worse than a two-workgroups-per-CU one that is a few per cent slower alone.  For the
