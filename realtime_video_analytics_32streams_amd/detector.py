@@ -127,6 +127,9 @@ class HipYoloDetector(BaseDetector):
         self._in_border: dict = {}                        # batch size -> frame geometry whose letterbox border the buffer holds
         self._post: Optional[ops.PostBuffers] = None      # result buffers of the latest call
         self._in: Optional[torch.Tensor] = None           # input tensor of the latest call
+        # PipelinedTicks runs the networks of consecutive ticks on two streams: input tensor, letterbox-border state and
+        # fused plan (its activation buffers) exist once per slot; everything else keeps using slot 0
+        self._slot = 0
         if config.warmup and self.net is not None:  # detector.py:588-593
             with torch.inference_mode():
                 self._infer(torch.zeros((1, 3, *self.input_hw), device=self.device,
@@ -134,11 +137,11 @@ class HipYoloDetector(BaseDetector):
 
     # -- stages ---------------------------------------------------------------------------------
     def _preprocess(self, frames: Sequence) -> tuple[torch.Tensor, N.Letterbox]:
-        n = len(frames)
+        n = len(frames) if self._slot == 0 else (len(frames), self._slot)      # buffer key: batch size (, slot)
         dt = torch.float16 if self.half else torch.float32
         self._in = self._in_bufs.get(n)
         if self._in is None:
-            self._in = self._in_bufs[n] = torch.empty((n, 3, *self.input_hw), dtype=dt, device=self.device)
+            self._in = self._in_bufs[n] = torch.empty((len(frames), 3, *self.input_hw), dtype=dt, device=self.device)
         f0 = frames[0]
         if isinstance(f0, ops.Nv12Surface):
             # the border (pad value) of the input tensor is constant per geometry: the first launch into a buffer writes it,
@@ -159,15 +162,26 @@ class HipYoloDetector(BaseDetector):
         """Drop cached fused plans (call after editing ``self.net``'s weights)."""
         self._plans.clear()
 
+    def plan_for(self, tensor: torch.Tensor):
+        """The fused plan of this batch shape and the current slot (built and autotuned on first use; a second slot's plan
+        takes over the first one's kernel selection instead of tuning again)."""
+        shape = (int(tensor.shape[0]), int(tensor.shape[2]), int(tensor.shape[3]))
+        key = shape if self._slot == 0 else shape + (self._slot,)
+        plan = self._plans.get(key)
+        if plan is None:
+            from .engine import FusedYoloV8
+            first = self._plans.get(shape) if self._slot else None
+            plan = self._plans[key] = FusedYoloV8(self.net, shape[0], shape[1:], device=self.device, ctx=self.ctx,
+                                                  autotune=first is None)
+            if first is not None:
+                plan.copy_tuning(first)
+        return plan
+
     def _infer(self, tensor: torch.Tensor) -> torch.Tensor:
         if self._infer_fn is not None:
             return self._infer_fn(tensor)
         if self.engine == "fused" and self.half and tensor.dtype == torch.float16:
-            key = (int(tensor.shape[0]), int(tensor.shape[2]), int(tensor.shape[3]))
-            plan = self._plans.get(key)
-            if plan is None:
-                from .engine import FusedYoloV8
-                plan = self._plans[key] = FusedYoloV8(self.net, key[0], key[1:], device=self.device, ctx=self.ctx)
+            plan = self.plan_for(tensor)
             return plan(tensor.contiguous())
         return self.net(tensor.contiguous(memory_format=torch.channels_last))
 

@@ -396,6 +396,14 @@ class FusedYoloV8:
         if os.environ.get("RVA_TUNE_IN_PLAN", "1") == "1":
             self._refine_in_plan()
 
+    def copy_tuning(self, other: "FusedYoloV8") -> None:
+        """Take over the kernel selection of a plan built from the same network and batch shape."""
+        assert len(self._tunable) == len(other._tunable)
+        for (_, mine, d1), (_, theirs, d2) in zip(self._tunable, other._tunable):
+            assert d1 == d2
+            mine["variant"] = theirs["variant"]
+        self.tuning = list(getattr(other, "tuning", []))
+
     def _refine_in_plan(self, reps: int = 12, within: float = 1.25) -> None:
         import os
         within = float(os.environ.get('RVA_TUNE_WITHIN', within))

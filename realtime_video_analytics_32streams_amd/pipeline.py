@@ -372,7 +372,7 @@ class PipelinedTicks:
     """
 
     def __init__(self, pipe: TickPipeline, depth: int = 2, use_graph: bool = True, overlap: bool = True,
-                 net_graph: bool = False):
+                 net_graph: bool = False, net_streams: int = 2):
         if any(not hasattr(d, "predict_batch_device") for d in pipe.detectors):
             raise NotImplementedError("PipelinedTicks needs detectors with a batched device path (temporal heads return host "
                                       "detections: use TickPipeline.tick)")
@@ -392,6 +392,15 @@ class PipelinedTicks:
         self.two_streams = (overlap or self.use_graph) and fused              # needs per-parity head tensors
         self.sA = torch.cuda.current_stream()
         self.sB = torch.cuda.Stream(device=self.det.device) if self.two_streams else self.sA
+        # The networks of consecutive ticks run on TWO streams (even ticks on A, odd ticks on A'), each with its own input
+        # tensor and fused plan: the tail of a forward pass (20x20 layers, detect branches: half the CUs idle) overlaps the
+        # head of the next one (stem, 160x160 / 80x80 layers).  Measured with the plan alone: 1.73 -> 1.54 ms per 32-frame
+        # forward pass (tools/two_streams.py).  A tick's K1 still waits for the previous tick's K1 / K5 (gate state, source
+        # rings), and its network for the tick two before it to have released the head tensors of its parity.
+        import os
+        net_streams = int(os.environ.get("RVA_NET_STREAMS", net_streams))      # A/B switch for measurements
+        self.net_streams = 2 if (net_streams == 2 and self.two_streams and depth == 2 and not self.net_graph) else 1
+        self.sAs = [self.sA, torch.cuda.Stream(device=self.det.device) if self.net_streams == 2 else self.sA]
         self._pending = [None, None]          # per parity: what the stream-B part of that tick needs
         self._meta = [None, None]             # per parity: (packets, t0) for collect_result
         self._next, self._oldest = 0, 0
@@ -408,10 +417,11 @@ class PipelinedTicks:
 
     # -- pieces of a tick -------------------------------------------------------------------------------------
     def _plan_of(self, det, tensor):
-        key = (int(tensor.shape[0]), int(tensor.shape[2]), int(tensor.shape[3]))
-        if key not in det._plans:
-            det._infer(tensor)                                     # builds + autotunes the plan (outside any capture)
-        return det._plans[key]
+        return det.plan_for(tensor)                                # builds + autotunes the plan of det's current slot (outside any capture)
+
+    def _set_slot(self, par):
+        for d in self.pipe.detectors:
+            d._slot = par if self.net_streams == 2 else 0
 
     def _post_part(self, plan, raws, metas, motion, events=None):
         """Stream-B work of one tick for every group: K2/K3 then K4 (+ filter, rescale, gates)."""
@@ -443,10 +453,12 @@ class PipelinedTicks:
         raws = [[None, None] for _ in plan.groups]
         for gi, g in enumerate(plan.groups):
             det = p.detectors[g.det]
-            fp = self._plan_of(det, tensors[gi])
             pair = []
             for par in (0, 1):
-                raws[gi][par] = fp.use_output(2 * gi + par)        # head tensor (group, parity): a stable buffer of the plan
+                self._set_slot(par)
+                fp = self._plan_of(det, tensors[gi])
+                # head tensor (group, parity): a stable buffer of the plan (two network streams: of the parity's own plan)
+                raws[gi][par] = fp.use_output(gi if self.net_streams == 2 else 2 * gi + par)
                 if self.net_graph:
                     gr = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(gr):
@@ -464,6 +476,7 @@ class PipelinedTicks:
                     self._ids_and_snapshot(par)                    # single GPU: ids + snapshot ride in the graph
             self._post_graphs[par] = gr
         torch.cuda.synchronize()
+        self._set_slot(0)
         self._cap_sig = plan.signature
         self._captured = True
 
@@ -499,40 +512,47 @@ class PipelinedTicks:
         t0 = time.perf_counter()
         if packets is None:
             packets = [src.next_packet() for src in p.sources]
-        packets = p._frames_for_detection(packets)                 # roi / downsample (device work on stream A)
-        plan = p.plan_tick(packets, process)
-        motion = p._device_gates(packets, par) if p.has_gates else None       # K5 + gate parameters (no sync)
-        sig = plan.signature
-        replay = self.use_graph and self.two_streams and self._cap_sig == sig
-        capture_after = self.use_graph and self.two_streams and not replay and sig in self._seen_sigs
-        tensors, metas, raws = [], [], []
-        for gi, g in enumerate(plan.groups):
-            det = p.detectors[g.det]
-            with torch.inference_mode():
-                if events and gi == 0: events[0].record()
-                if before_k1 and gi == 0: before_k1()
-                tensor, meta = det._preprocess([packets[i].frame for i in g.idx])      # K1
-                if events and gi == 0: events[1].record()
-            if self.two_streams and gi == 0:
-                self._k1_done[par].record(self.sA)
-                if k >= 2:
-                    self.sA.wait_event(self._done[par])            # tick k-2 has finished reading the head tensors `par`
-            tensors.append(tensor); metas.append(meta)
-            if replay and self.net_graph:
-                self._net_graphs[gi][par].replay()
-            else:
+        sa = self.sAs[par]
+        self._set_slot(par)
+        with torch.cuda.stream(sa):
+            if self.net_streams == 2 and k >= 1:
+                sa.wait_event(self._k1_done[par ^ 1])              # the previous tick's K5 / K1 (gate state, source rings) first
+            packets = p._frames_for_detection(packets)             # roi / downsample (device work on stream A)
+            plan = p.plan_tick(packets, process)
+            motion = p._device_gates(packets, par) if p.has_gates else None       # K5 + gate parameters (no sync)
+            sig = plan.signature
+            replay = self.use_graph and self.two_streams and self._cap_sig == sig
+            capture_after = self.use_graph and self.two_streams and not replay and sig in self._seen_sigs
+            tensors, metas, raws = [], [], []
+            for gi, g in enumerate(plan.groups):
+                det = p.detectors[g.det]
                 with torch.inference_mode():
-                    if self.two_streams:
-                        self._plan_of(det, tensor).use_output(2 * gi + par)
-                    raws.append(det._infer(tensor))
-        if events: events[2].record()
-        self._pending[par] = ("graph" if replay else "eager", plan, None if replay else raws, metas, motion,
-                              None if replay else events)
-        self._meta[par] = (packets, t0)
+                    if events and gi == 0: events[0].record()
+                    if before_k1 and gi == 0: before_k1()
+                    tensor, meta = det._preprocess([packets[i].frame for i in g.idx])      # K1
+                    if events and gi == 0: events[1].record()
+                if self.two_streams and gi == 0:
+                    self._k1_done[par].record(sa)
+                    if k >= 2:
+                        sa.wait_event(self._done[par])             # tick k-2 has finished reading the head tensors `par`
+                tensors.append(tensor); metas.append(meta)
+                if replay and self.net_graph:
+                    self._net_graphs[gi][par].replay()
+                else:
+                    with torch.inference_mode():
+                        if self.two_streams:
+                            self._plan_of(det, tensor).use_output(gi if self.net_streams == 2 else 2 * gi + par)
+                        raws.append(det._infer(tensor))
+            if events: events[2].record()
+            self._pending[par] = ("graph" if replay else "eager", plan, None if replay else raws, metas, motion,
+                                  None if replay else events)
+            self._meta[par] = (packets, t0)
+            if self.two_streams:
+                if not plan.groups:
+                    self._k1_done[par].record(sa)
+                self._net_done[par].record(sa)
+        self._set_slot(0)
         if self.two_streams:
-            if not plan.groups:
-                self._k1_done[par].record(self.sA)
-            self._net_done[par].record(self.sA)
             if self.depth == 1:
                 self._issue_post(k, None)
             elif k >= 1 and self._posted < k - 1:

@@ -66,8 +66,11 @@ def test_bench_configuration_end_to_end_against_the_oracle():
     def check(k):
         nonlocal plan, checked
         _, tables = runner.collect()
-        plan = plan or det._plans[(S, 640, 640)]
-        head = plan._outs[k & 1].float().cpu().numpy()            # tick k's head tensor: intact until tick k+2's network
+        if runner.net_streams == 2:      # even / odd ticks run on their own plan (slot 0 / 1), head tensor 0 of that plan
+            head = det._plans[(S, 640, 640) if k % 2 == 0 else (S, 640, 640, 1)]._outs[0].float().cpu().numpy()
+        else:
+            plan = plan or det._plans[(S, 640, 640)]
+            head = plan._outs[k & 1].float().cpu().numpy()        # tick k's head tensor: intact until tick k+2's network
         for s in range(S):                                         # canonical order: tick-major, stream-minor
             r = orc.postprocess(head[s], det.config.confidence_threshold, det.config.iou_threshold, None, (1920, 1080))
             m = r["conf"].astype(np.float64) >= det.config.confidence_threshold          # filter_detections
