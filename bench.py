@@ -304,6 +304,10 @@ def main():
                       "k2k3_postprocess": round(float(post_ms), 4), "k4_tracker": round(float(trk_ms), 4)},
         "detections_per_frame": round(dets_emitted / S, 2), "tracks_per_stream": round(n_tracks / (K * S), 2),
         "detector_tflops": round(net_tflops, 2), "detector_frac_of_mfma_peak": round(net_tflops / MFMA_PEAK_TFLOPS, 4),
+        # one forward pass alone (the eager per-stage pass) above; below: the network FLOPs of a tick over the tick period of the
+        # timed region, where the forward passes of consecutive ticks overlap on two streams
+        "detector_tflops_in_pipeline": round(2 * macs * S / (elapsed / K) / 1e12, 2),
+        "detector_frac_of_mfma_peak_in_pipeline": round(2 * macs * S / (elapsed / K) / 1e12 / MFMA_PEAK_TFLOPS, 4),
         "roofline": {"kernel": "k1_ratio_content<3,half,2> (NV12 1080p -> content rows of fp16 3x640x640, one launch per tick; the "
                                "constant letterbox border was written by the first launch into the buffer)", "bound": "hbm",
                      "achieved": round(k1_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -16,6 +16,7 @@ be captured into a hipGraph.  Self-parity against the torch module is a test (fp
 from __future__ import annotations
 
 import ctypes as C
+import time
 from typing import Callable, Dict, List, Optional, Tuple
 
 import torch
@@ -58,6 +59,7 @@ class FusedYoloV8:
         self.B, self.H, self.W = batch, hw[0], hw[1]
         assert hw[0] % 32 == 0 and hw[1] % 32 == 0
         net = net.fuse()
+        self._net = net                     # kept for the twin plan of the in-plan kernel selection
         self.nc = net.nc
         self.L = N.lib()
         self._keep: List[torch.Tensor] = []
@@ -413,18 +415,34 @@ class FusedYoloV8:
         layers with runners-up within 25 % the whole forward pass is timed with each candidate (coordinate descent, most
         expensive layers first) and a candidate is kept when the pass gets faster by more than the timing noise."""
         x = torch.zeros((self.B, 3, self.H, self.W), dtype=torch.float16, device=self.dev)
+        # The objective is what the pipeline does with the plan: forward passes of consecutive ticks alternate between two
+        # streams and overlap (PipelinedTicks), so the pass is timed as a pair -- this plan on one stream, a twin with the same
+        # kernel selection on another.  RVA_TUNE_OVERLAP=0: a single pass alone.
+        twin = None
+        lanes = self.concurrent_heads
+        if os.environ.get("RVA_TUNE_OVERLAP", "1") == "1":
+            twin = FusedYoloV8(self._net, self.B, (self.H, self.W), device=self.dev, ctx=self.ctx, autotune=False)
+            s1, s2 = torch.cuda.Stream(device=self.dev), torch.cuda.Stream(device=self.dev)
+            self.concurrent_heads = twin.concurrent_heads = False      # as PipelinedTicks runs overlapping passes: branches in line
 
         def forward_us() -> float:
             best = float("inf")
+            if twin is not None:
+                twin.copy_tuning(self)
             for _ in range(2):
                 torch.cuda.synchronize()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(reps):
-                    self(x)
-                e1.record()
+                t0 = time.perf_counter()
+                if twin is None:
+                    for _ in range(reps):
+                        self(x)
+                else:
+                    for _ in range(reps // 2):
+                        with torch.cuda.stream(s1):
+                            self(x)
+                        with torch.cuda.stream(s2):
+                            twin(x)
                 torch.cuda.synchronize()
-                best = min(best, e0.elapsed_time(e1) / reps * 1e3)
+                best = min(best, (time.perf_counter() - t0) / (reps // 2 * 2 if twin is not None else reps) * 1e6)
             return best
         by_desc: Dict[str, list] = {}
         for _, state, desc in self._tunable:
@@ -433,6 +451,7 @@ class FusedYoloV8:
         order = [d for d in sorted(cost, key=cost.get, reverse=True)
                  if len(self._candidates[d]) > 1 and self._candidates[d][1][0] <= within * self._candidates[d][0][0]][:24]
         if not order:
+            self.concurrent_heads = lanes
             return
         self(x); self(x)
         base = forward_us()
@@ -457,6 +476,7 @@ class FusedYoloV8:
                             st["variant"] = cur
             if not changed:
                 break
+        self.concurrent_heads = lanes
         iso = {d: {v: us for us, v in c} for d, c in self._candidates.items()}
         self.tuning = [(d, by_desc[d][0]["variant"], round(iso[d].get(by_desc[d][0]["variant"], us), 1)) for d, _, us in self.tuning]
 

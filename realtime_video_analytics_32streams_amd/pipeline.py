@@ -29,6 +29,7 @@ Multi-GPU: each rank owns a contiguous slice of the streams; the only exchange i
 """
 from __future__ import annotations
 
+import os
 import time
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -400,7 +401,17 @@ class PipelinedTicks:
         import os
         net_streams = int(os.environ.get("RVA_NET_STREAMS", net_streams))      # A/B switch for measurements
         self.net_streams = 2 if (net_streams == 2 and self.two_streams and depth == 2 and not self.net_graph) else 1
-        self.sAs = [self.sA, torch.cuda.Stream(device=self.det.device) if self.net_streams == 2 else self.sA]
+        # Two explicit streams created back to back (the runtime spreads consecutive streams over its hardware queues; the
+        # caller's stream may be the null stream, whose queue another stream can share -- then the two networks would
+        # serialise: 17.9 k instead of 20.3 k frames/s).  In this mode the plans run their detect branches in line: with two
+        # forward passes in flight the side streams add nothing and, spread over more hardware queues, cost up to 25 %
+        # (tools/ab_queues_plan.sh: 1.53-1.55 ms per pass in line for 3-16 queues, 1.68-1.82 ms with side streams).
+        if self.net_streams == 2:
+            self.sAs = [torch.cuda.Stream(device=self.det.device), torch.cuda.Stream(device=self.det.device)]
+        else:
+            self.sAs = [self.sA, self.sA]
+        self.sK = None                        # K1 / K5 ride on the tick's network stream
+        self._k1_group_done = [[], []]        # per parity: one event per frame group (only used with a separate K1 stream)
         self._pending = [None, None]          # per parity: what the stream-B part of that tick needs
         self._meta = [None, None]             # per parity: (packets, t0) for collect_result
         self._next, self._oldest = 0, 0
@@ -417,7 +428,10 @@ class PipelinedTicks:
 
     # -- pieces of a tick -------------------------------------------------------------------------------------
     def _plan_of(self, det, tensor):
-        return det.plan_for(tensor)                                # builds + autotunes the plan of det's current slot (outside any capture)
+        plan = det.plan_for(tensor)                                # builds + autotunes the plan of det's current slot (outside any capture)
+        if self.net_streams == 2 and os.environ.get("RVA_NET2_LANES", "0") != "1":
+            plan.concurrent_heads = False                          # detect branches in line (see __init__)
+        return plan
 
     def _set_slot(self, par):
         for d in self.pipe.detectors:
@@ -480,12 +494,13 @@ class PipelinedTicks:
         self._cap_sig = plan.signature
         self._captured = True
 
-    def _issue_post(self, k, after):
+    def _issue_post(self, k, after, stream=None):
         par = k & 1
-        with torch.cuda.stream(self.sB):
-            self.sB.wait_event(self._net_done[par])
+        sb = stream if stream is not None else self.sB
+        with torch.cuda.stream(sb):
+            sb.wait_event(self._net_done[par])
             if after is not None:
-                self.sB.wait_event(after)
+                sb.wait_event(after)
             mode, plan, raws, metas, motion, events = self._pending[par]
             if mode == "graph":
                 self._post_graphs[par].replay()
@@ -494,7 +509,7 @@ class PipelinedTicks:
             else:
                 self._post_part(plan, raws, metas, motion, events)
                 self._ids_and_snapshot(k, events)
-            self._done[par].record(self.sB)
+            self._done[par].record(sb)
         self._posted = k
 
     # -- API ----------------------------------------------------------------------------------------------------
@@ -513,28 +528,41 @@ class PipelinedTicks:
         if packets is None:
             packets = [src.next_packet() for src in p.sources]
         sa = self.sAs[par]
+        sk = self.sK if self.sK is not None else sa               # where roi / downsample / K5 / K1 run
         self._set_slot(par)
-        with torch.cuda.stream(sa):
-            if self.net_streams == 2 and k >= 1:
-                sa.wait_event(self._k1_done[par ^ 1])              # the previous tick's K5 / K1 (gate state, source rings) first
-            packets = p._frames_for_detection(packets)             # roi / downsample (device work on stream A)
+        if self.net_streams == 2:
+            sa.wait_stream(torch.cuda.current_stream())            # whatever the caller queued before this tick (frame sources)
+        with torch.cuda.stream(sk):
+            if self.net_streams == 2:
+                if k >= 1:
+                    sk.wait_event(self._k1_done[par ^ 1])          # the previous tick's K5 / K1 (gate state, source rings) first
+                if k >= 2:
+                    sk.wait_event(self._net_done[par])             # tick k-2's network has read the input tensors of this slot
+            packets = p._frames_for_detection(packets)             # roi / downsample (device work)
             plan = p.plan_tick(packets, process)
             motion = p._device_gates(packets, par) if p.has_gates else None       # K5 + gate parameters (no sync)
-            sig = plan.signature
-            replay = self.use_graph and self.two_streams and self._cap_sig == sig
-            capture_after = self.use_graph and self.two_streams and not replay and sig in self._seen_sigs
-            tensors, metas, raws = [], [], []
-            for gi, g in enumerate(plan.groups):
-                det = p.detectors[g.det]
-                with torch.inference_mode():
-                    if events and gi == 0: events[0].record()
-                    if before_k1 and gi == 0: before_k1()
-                    tensor, meta = det._preprocess([packets[i].frame for i in g.idx])      # K1
-                    if events and gi == 0: events[1].record()
+        sig = plan.signature
+        replay = self.use_graph and self.two_streams and self._cap_sig == sig
+        capture_after = self.use_graph and self.two_streams and not replay and sig in self._seen_sigs
+        tensors, metas, raws = [], [], []
+        while len(self._k1_group_done[par]) < len(plan.groups):
+            self._k1_group_done[par].append(torch.cuda.Event())
+        for gi, g in enumerate(plan.groups):
+            det = p.detectors[g.det]
+            with torch.cuda.stream(sk), torch.inference_mode():
+                if events and gi == 0: events[0].record()
+                if before_k1 and gi == 0: before_k1()
+                tensor, meta = det._preprocess([packets[i].frame for i in g.idx])      # K1
+                if events and gi == 0: events[1].record()
+                if sk is not sa:
+                    self._k1_group_done[par][gi].record(sk)
                 if self.two_streams and gi == 0:
-                    self._k1_done[par].record(sa)
-                    if k >= 2:
-                        sa.wait_event(self._done[par])             # tick k-2 has finished reading the head tensors `par`
+                    self._k1_done[par].record(sk)
+            with torch.cuda.stream(sa):
+                if sk is not sa:
+                    sa.wait_event(self._k1_group_done[par][gi])
+                if self.two_streams and gi == 0 and k >= 2:
+                    sa.wait_event(self._done[par])                 # tick k-2 has finished reading the head tensors `par`
                 tensors.append(tensor); metas.append(meta)
                 if replay and self.net_graph:
                     self._net_graphs[gi][par].replay()
@@ -543,18 +571,25 @@ class PipelinedTicks:
                         if self.two_streams:
                             self._plan_of(det, tensor).use_output(gi if self.net_streams == 2 else 2 * gi + par)
                         raws.append(det._infer(tensor))
+        with torch.cuda.stream(sa):
             if events: events[2].record()
             self._pending[par] = ("graph" if replay else "eager", plan, None if replay else raws, metas, motion,
                                   None if replay else events)
             self._meta[par] = (packets, t0)
             if self.two_streams:
                 if not plan.groups:
-                    self._k1_done[par].record(sa)
+                    self._k1_done[par].record(sk)
                 self._net_done[par].record(sa)
         self._set_slot(0)
         if self.two_streams:
             if self.depth == 1:
                 self._issue_post(k, None)
+            elif self.net_streams == 2 and os.environ.get("RVA_TAIL_INLINE", "1") == "1":
+                # two network streams: the tail goes right behind its own network on the same stream -- a tick is one chain
+                # K1 -> network -> K2/K3 -> K4 -> ids -> snapshot, even and odd ticks on two streams (a third stream for the
+                # tails measured 3 % slower: 19.06 k against 19.70 k frames/s, and made the result depend on how the runtime
+                # spreads streams over its hardware queues)
+                self._issue_post(k, None, stream=sa)
             elif k >= 1 and self._posted < k - 1:
                 self._issue_post(k - 1, self._k1_done[par])        # K1 of this tick first, then the previous tail
         else:
