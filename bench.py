@@ -299,7 +299,7 @@ def main():
         "p99_latency_ms": round(float(np.percentile(lat, 99)) * 1e3, 3),
         "p50_latency_ms": round(float(np.percentile(lat, 50)) * 1e3, 3),
         "max_latency_ms": round(float(lat.max()) * 1e3, 3), "latency_samples": int(K),
-        "ticks_in_flight": args.depth, "network_streams": runner.net_streams, "hip_graph": bool(use_graph), "hip_graph_scope": ("network + tail" if args.net_graph else "post-process / tracker tail (network launched eagerly: concurrent detect branches)") if use_graph else None, "realtime_32x30fps": bool(fps / world >= 30.0 * S and np.percentile(lat, 99) < 1 / 30),
+        "ticks_in_flight": args.depth, "network_streams": runner.net_streams, "hip_graph": bool(use_graph), "hip_graph_scope": ("network + tail" if args.net_graph else ("post-process / tracker tail (networks launched eagerly; a tick is one chain on its own stream, even / odd ticks on two streams)" if runner.net_streams == 2 else "post-process / tracker tail (network launched eagerly: concurrent detect branches)")) if use_graph else None, "realtime_32x30fps": bool(fps / world >= 30.0 * S and np.percentile(lat, 99) < 1 / 30),
         "stages_ms": {"k1_preprocess": round(float(k1_ms), 4), "detector": round(float(net_ms), 4),
                       "k2k3_postprocess": round(float(post_ms), 4), "k4_tracker": round(float(trk_ms), 4)},
         "detections_per_frame": round(dets_emitted / S, 2), "tracks_per_stream": round(n_tracks / (K * S), 2),
