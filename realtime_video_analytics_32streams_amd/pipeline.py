@@ -499,6 +499,8 @@ class PipelinedTicks:
         sb = stream if stream is not None else self.sB
         with torch.cuda.stream(sb):
             sb.wait_event(self._net_done[par])
+            if stream is not None and k >= 1:
+                sb.wait_event(self._done[par ^ 1])                 # tails on two streams: tracker state is touched in tick order
             if after is not None:
                 sb.wait_event(after)
             mode, plan, raws, metas, motion, events = self._pending[par]
