@@ -22,6 +22,12 @@ import sys
 import time
 from pathlib import Path
 
+# The HIP runtime spreads streams over GPU_MAX_HW_QUEUES hardware queues (4 by default) in order of first use; two streams that
+# share a queue serialise.  The pipeline needs its two tick chains on different queues: with 8 queues the measured throughput is
+# the same as with 4 (19.9 k frames/s) and further streams in the process (RCCL's, under torch.distributed) cannot push the two
+# chains onto one queue as easily.  Must be set before the runtime initialises; an explicit setting of the caller wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 import torch
 
