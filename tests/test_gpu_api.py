@@ -268,11 +268,14 @@ def test_resnet_classifier_topk():
     assert hi.predict(FramePacket(st, frames[0], 0, 0.0)) == []
 
 
-@pytest.mark.parametrize("depth,graph", [(1, False), (2, False), (1, True), (2, True)], ids=["d1-eager", "d2-eager", "d1-graph", "d2-graph"])
-def test_pipelined_ticks_equal_synchronous_ticks(depth, graph):
-    """The throughput mode (two HIP streams, captured hipGraphs, two ticks in flight) yields the same track tables,
-    ids included, as TickPipeline.tick() on the same frames -- same detector object (same autotuned plan) on both
-    sides, separate trackers."""
+@pytest.mark.parametrize("depth,graph,chains", [(1, False, 1), (2, False, 2), (1, True, 1), (2, True, 2), (2, False, 1), (2, True, 1)],
+                         ids=["d1-eager", "d2-eager-two-chains", "d1-graph", "d2-graph-two-chains", "d2-eager-one-network-stream",
+                              "d2-graph-one-network-stream"])
+def test_pipelined_ticks_equal_synchronous_ticks(depth, graph, chains):
+    """The throughput mode (two ticks in flight, captured hipGraphs; a tick as one chain on its own stream -- even / odd ticks
+    on two streams, each with its own input tensor and plan -- or the round-1 layout with one network stream and one stream
+    for the tails) yields the same track tables, ids included, as TickPipeline.tick() on the same frames -- same detector
+    object (same kernel selection) on both sides, separate trackers."""
     from realtime_video_analytics_32streams_amd.pipeline import PipelinedTicks
     streams, det, trk, srcs = _make_pipe(4)
     sync = TickPipeline(streams, det, trk, sources=srcs)
@@ -280,7 +283,8 @@ def test_pipelined_ticks_equal_synchronous_ticks(depth, graph):
     srcs2 = [SyntheticNv12Stream(s, index=i, n_unique=3) for i, s in enumerate(streams)]
     for s in srcs2:
         s.open_sync()
-    runner = PipelinedTicks(TickPipeline(streams, det, trk2, sources=srcs2), depth=depth, use_graph=graph)
+    runner = PipelinedTicks(TickPipeline(streams, det, trk2, sources=srcs2), depth=depth, use_graph=graph, net_streams=chains)
+    assert runner.net_streams == chains
     T = 7
     want = []
     for _ in range(T):
