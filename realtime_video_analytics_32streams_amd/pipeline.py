@@ -410,8 +410,6 @@ class PipelinedTicks:
             self.sAs = [torch.cuda.Stream(device=self.det.device), torch.cuda.Stream(device=self.det.device)]
         else:
             self.sAs = [self.sA, self.sA]
-        self.sK = None                        # K1 / K5 ride on the tick's network stream
-        self._k1_group_done = [[], []]        # per parity: one event per frame group (only used with a separate K1 stream)
         self._pending = [None, None]          # per parity: what the stream-B part of that tick needs
         self._meta = [None, None]             # per parity: (packets, t0) for collect_result
         self._next, self._oldest = 0, 0
@@ -530,7 +528,8 @@ class PipelinedTicks:
         if packets is None:
             packets = [src.next_packet() for src in p.sources]
         sa = self.sAs[par]
-        sk = self.sK if self.sK is not None else sa               # where roi / downsample / K5 / K1 run
+        sk = sa                                                    # roi / downsample / K5 / K1 ride on the tick's own stream (a separate,
+                                                                   # even high-priority, stream for them cost 20 % of the throughput)
         self._set_slot(par)
         if self.net_streams == 2:
             sa.wait_stream(torch.cuda.current_stream())            # whatever the caller queued before this tick (frame sources)
@@ -547,8 +546,6 @@ class PipelinedTicks:
         replay = self.use_graph and self.two_streams and self._cap_sig == sig
         capture_after = self.use_graph and self.two_streams and not replay and sig in self._seen_sigs
         tensors, metas, raws = [], [], []
-        while len(self._k1_group_done[par]) < len(plan.groups):
-            self._k1_group_done[par].append(torch.cuda.Event())
         for gi, g in enumerate(plan.groups):
             det = p.detectors[g.det]
             with torch.cuda.stream(sk), torch.inference_mode():
@@ -556,13 +553,9 @@ class PipelinedTicks:
                 if before_k1 and gi == 0: before_k1()
                 tensor, meta = det._preprocess([packets[i].frame for i in g.idx])      # K1
                 if events and gi == 0: events[1].record()
-                if sk is not sa:
-                    self._k1_group_done[par][gi].record(sk)
                 if self.two_streams and gi == 0:
                     self._k1_done[par].record(sk)
             with torch.cuda.stream(sa):
-                if sk is not sa:
-                    sa.wait_event(self._k1_group_done[par][gi])
                 if self.two_streams and gi == 0 and k >= 2:
                     sa.wait_event(self._done[par])                 # tick k-2 has finished reading the head tensors `par`
                 tensors.append(tensor); metas.append(meta)
