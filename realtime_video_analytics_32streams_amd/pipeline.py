@@ -384,6 +384,7 @@ class PipelinedTicks:
         self.world_sharded = pipe.id_sync is not None
         fused = all(d.engine == "fused" and d.half and d._infer_fn is None for d in pipe.detectors)
         self.use_graph = bool(use_graph) and fused
+        self._fused = fused
         # The network itself is launched eagerly by default: its plan forks the detect branches onto side streams, which
         # run concurrently when launched eagerly but are serialised by the hipGraph executor of this ROCm (measured:
         # 17.2 k vs 16.0 k frames/s); ~75 launches per tick cost the host ~0.3 ms of a 1.9 ms tick.  The latency-bound
@@ -427,8 +428,9 @@ class PipelinedTicks:
     # -- pieces of a tick -------------------------------------------------------------------------------------
     def _plan_of(self, det, tensor):
         plan = det.plan_for(tensor)                                # builds + autotunes the plan of det's current slot (outside any capture)
-        if self.net_streams == 2 and os.environ.get("RVA_NET2_LANES", "0") != "1":
-            plan.concurrent_heads = False                          # detect branches in line (see __init__)
+        # detect branches in line when two passes overlap (see __init__), on side streams when one pass runs at a time
+        plan.concurrent_heads = os.environ.get("RVA_SERIAL_HEADS") != "1" and \
+            (self.net_streams != 2 or os.environ.get("RVA_NET2_LANES", "0") == "1")
         return plan
 
     def _set_slot(self, par):
@@ -565,6 +567,8 @@ class PipelinedTicks:
                     with torch.inference_mode():
                         if self.two_streams:
                             self._plan_of(det, tensor).use_output(gi if self.net_streams == 2 else 2 * gi + par)
+                        elif self._fused:
+                            self._plan_of(det, tensor)             # sets the plan's branch mode for this runner's layout
                         raws.append(det._infer(tensor))
         with torch.cuda.stream(sa):
             if events: events[2].record()
