@@ -2,14 +2,16 @@
 """Headline benchmark: aggregate detected FPS across streams + p99 per-frame latency, 32x1080p30.
 
 One *step* = one tick of the hot path over one batch of synthetic input on every GPU:
-32 x 1080p NV12 surfaces resident in HBM -> K1 pre-process -> YOLOv8s fp16 (PyTorch-ROCm) -> K2 decode
+32 x 1080p NV12 surfaces resident in HBM -> K1 pre-process -> YOLOv8s fp16 (librva fused MFMA plan) -> K2 decode
 + K3 NMS -> K4 tracker update + id assignment -> tracks read back to the host (BASELINE.json
 configs[2], the headline single-GPU configuration).  With --gpus N every rank runs 32 streams of its
 own (weak scaling) and the ranks exchange one 128-byte all-gather of new-track counts per tick over
 RCCL so that track ids stay globally consistent.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) including
-  "roofline"     the K1 pre-process kernel against the HBM roofline (3,840,000 algorithmic B/frame),
+  "roofline"     the steady-state K1 pre-process kernel against the HBM roofline (2,764,800 algorithmic B/frame: the
+                 source rows it reads + the 360 content rows it writes; the first launch into a buffer also writes the
+                 constant letterbox border: 3,840,000 B/frame, reported beside it as "full_tensor_kernel"),
   "cpu_baseline" the CPU oracle (oracle/, kind "port") + torch-CPU fp32 network on a bounded sample.
 Decode is NOT part of the step: librocdecode and an H.265 source are absent (reported as such).
 """
@@ -64,8 +66,6 @@ def parse():
                          "post-process / tracker load sweep)")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames in the CPU-baseline sample (0 = auto)")
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark = True")
-    ap.add_argument("--engine", default="fused", choices=["fused", "torch"],
-                    help="detector network: librva fused plan (MFMA conv + fused epilogues) or torch/MIOpen")
     ap.add_argument("--no-graph", action="store_true",
                     help="launch every kernel eagerly instead of replaying the captured hipGraph of the post-process / tracker tail")
     ap.add_argument("--net-graph", action="store_true",
@@ -170,7 +170,7 @@ def main():
     net_cpu = build_detector_net(args.model, seed=0)
     macs = count_macs(net_cpu)
     import copy
-    det = HipYoloDetector(dcfg, net=copy.deepcopy(net_cpu), device=local, engine=args.engine)
+    det = HipYoloDetector(dcfg, net=copy.deepcopy(net_cpu), device=local)
     # synthetic weights: shift the class biases so a realistic number of anchors clears the threshold
     with torch.inference_mode():
         sample, _ = ops.preprocess_nv12([src._ring[0] for src in sources[:8]], (640, 640), half=True)
@@ -200,7 +200,7 @@ def main():
 
     # ---- warm-up (untimed), through the same runner as the timed region: the first tick sizes every buffer and
     # autotunes the plan eagerly, the second one captures the hipGraphs, the rest replay them -----------------
-    use_graph = (not args.no_graph) and args.engine == "fused"
+    use_graph = not args.no_graph
     from realtime_video_analytics_32streams_amd.pipeline import PipelinedTicks
     runner = PipelinedTicks(pipe, depth=args.depth, use_graph=use_graph, net_graph=args.net_graph)
     # at least 20 untimed ticks: the first one builds and tunes the plan, the second builds the odd ticks' plan, the third captures
@@ -302,7 +302,7 @@ def main():
         "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": "f16", "data": "synthetic",
         "config": {"workload": workload,
-                   "streams_per_gpu": S, "detector": f"yolov8{args.model}", "detector_engine": args.engine, "input": [640, 640],
+                   "streams_per_gpu": S, "detector": f"yolov8{args.model}", "detector_engine": det.engine, "input": [640, 640],
                    "weights": "seeded random, class biases calibrated to ~%d candidates/frame" % args.target_dets,
                    "conf": args.conf, "iou": args.iou, "tracker": {"max_age": 30, "max_iou_distance": 0.5, "min_hits": 1},
                    "decode": "not measured: " + rocdecode_status()},
@@ -464,6 +464,7 @@ def cpu_baseline(args, net_cpu, shifts, sources, dcfg, tcfg):
     sample with the frames spread over all host cores (what N reference processes could reach)."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle as orc
+    from realtime_video_analytics_32streams_amd.yolov8 import count_macs
     S = len(sources)
     n = args.cpu_frames or min(S, 16)
     cores = os.cpu_count() or 1
@@ -484,8 +485,22 @@ def cpu_baseline(args, net_cpu, shifts, sources, dcfg, tcfg):
         m = r["conf"].astype(np.float64) >= dcfg.confidence_threshold
         return r["boxes"][m].astype(np.float64), r["conf"][m].astype(np.float64), r["cls"][m].astype(np.int64)
 
-    # leg 1: oracle stages on one thread, network on all torch threads
-    nthr = int(torch.get_num_threads())
+    # the network leg first, on its own: one untimed warm-up call (oneDNN primitive creation, thread pool start), then a small
+    # sweep over torch's intra-op thread count -- a 256-core host is not fastest with 128 threads on a 16-image batch
+    x_net = torch.from_numpy(np.stack([pre(f) for f in frames]))
+    nthr0 = int(torch.get_num_threads())
+    sweep = {}
+    with torch.inference_mode():
+        net(x_net[:2])
+        for t in sorted({min(t, cores) for t in (16, 32, 64, nthr0, cores)}):
+            torch.set_num_threads(t)
+            net(x_net[:2])
+            a = time.perf_counter()
+            net(x_net)
+            sweep[t] = time.perf_counter() - a
+    nthr = min(sweep, key=sweep.get)
+    torch.set_num_threads(nthr)
+    # leg 1: oracle stages on one thread, network on the best torch thread count
     trk = orc.Tracker(n, tcfg.max_age, tcfg.max_iou_distance, tcfg.min_hits)
     t0 = time.perf_counter()
     tens = np.stack([pre(f) for f in frames])
@@ -510,10 +525,14 @@ def cpu_baseline(args, net_cpu, shifts, sources, dcfg, tcfg):
         for i in range(n):                                     # the tracker tables are per stream: one update each
             trk2.update(i, *dets[i])
         u3 = time.perf_counter()
+    torch.set_num_threads(nthr0)
+    gflop = 2.0 * count_macs(net) * n / 1e9
     return {"value": round(n / (u3 - u0), 2), "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"{n} frames of the same workload through oracle/rva_oracle.c (pre/post/tracker) + the same "
                       f"YOLOv8{args.model} in torch CPU fp32; NOT OpenCV+ONNXRuntime (neither is installed).  `value` is the "
-                      f"all-cores leg ({workers} oracle threads, {nthr} torch threads)",
+                      f"all-cores leg ({workers} oracle threads, {nthr} torch threads = the fastest of the sweep, after a warm-up call)",
+            "torch_thread_sweep_s": {str(k): round(v, 3) for k, v in sweep.items()},
+            "detector_cpu_gflops": round(gflop / (u2 - u1), 1),
             "legs": {"one_oracle_thread": {"frames_per_s": round(n / (t3 - t0), 2), "threads": {"oracle": 1, "torch": nthr},
                                            "seconds": {"preprocess": round(t1 - t0, 3), "detector": round(t2 - t1, 3),
                                                        "post_tracker": round(t3 - t2, 3)}},

@@ -56,6 +56,15 @@ struct ConvArgs {
     int H, W, Cin, CinPad, Ho, Wo, Cout, stride, M, act, n_tiles, m_tiles;   // CinPad = Cin rounded up to 32 (weight rows are zero-padded)
 };
 
+// Timing-only ablation switches (skip the MFMA phase / the prefetch loads / the epilogue) exist in the private diagnostic
+// build only (tools/row_stamps.py compiles with -DRVA_ROW_STAMPS); the shipped library has neither the fields nor the reads.
+#ifdef RVA_ROW_STAMPS
+#define RVA_DBG_FIELD int dbg;
+#define RVA_DBG(a, bit) ((a).dbg & (bit))
+#else
+#define RVA_DBG_FIELD
+#define RVA_DBG(a, bit) 0
+#endif
 #ifdef RVA_ROW_STAMPS
 // tuning aid (tools/row_stamps.py builds a private library with this macro): per-phase s_memtime stamps of a few blocks
 __device__ unsigned long long g_stamps[8][256];
@@ -491,7 +500,7 @@ struct ResArgs {
     __half *out; int ldo;
     const __half *res; int ldr;
     int H, W, Cin, CinPad, Cout, act, n_tiles, tiles_per_img, total_tiles, tile_rows, M;
-    int dbg;   // timing-only ablation switches (RVA_CONV_DBG): 1 = skip MFMA phase, 2 = skip prefetch loads, 4 = skip epilogue
+    RVA_DBG_FIELD   // diagnostic build: 1 = skip MFMA phase, 2 = skip prefetch loads, 4 = skip epilogue
 };
 
 template <int BN, int WPX, int KS, int CK, int NA>
@@ -597,7 +606,7 @@ __global__ void __launch_bounds__(256, 1) k_conv_res(ResArgs a)
         if (ncc == cpt) { ncc = 0; nt = t + gridDim.x; }
         const bool has_next = nt < a.total_tiles;
         Tile TN = T;
-        if (has_next && !(a.dbg & 2)) {
+        if (has_next && !RVA_DBG(a, 2)) {
             if (nt != t) TN = decode(nt);
             prefetch_act(TN, ncc);
             prefetch_w(TN.n0, ncc);   // unconditional: a conditional definition keeps the staging array in scratch
@@ -618,7 +627,7 @@ __global__ void __launch_bounds__(256, 1) k_conv_res(ResArgs a)
         const __half *wb = wT + (size_t)(lane & 15) * ROW + (lane >> 4) * 8;
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
-            if (a.dbg & 1) break;
+            if (RVA_DBG(a, 1)) break;
             const int toff = KS == 3 ? ((tap / 3) * W2 + (tap % 3)) * ROW : 0;
 #pragma unroll 1
             for (int ks = 0; ks < KSTEPS; ++ks) {
@@ -635,7 +644,7 @@ __global__ void __launch_bounds__(256, 1) k_conv_res(ResArgs a)
             }
         }
         __syncthreads();                                   // every wave is done reading this item's operands
-        if (cc == cpt - 1 && !(a.dbg & 4)) {
+        if (cc == cpt - 1 && !RVA_DBG(a, 4)) {
             // ---- epilogue of the tile: bias + SiLU, transpose through LDS, vector stores (+ residual)
             constexpr int SROW = BN + 8;
             __half *stage = (__half *)smem;
@@ -727,7 +736,7 @@ hipError_t launch_res(ResArgs &a, int batch, int num_cus, hipStream_t s)
 struct StemArgs {
     const __half *in; const float *w; const float *bias; __half *out;   // w: [Cout][27] (c, ky, kx)
     int B, H, W, Ho, Wo, Cout, ldo;
-    int dbg;
+    RVA_DBG_FIELD
 };
 
 __global__ void __launch_bounds__(256) k_stem(StemArgs a, const __half *__restrict__ gw, const float *__restrict__ gb)
@@ -783,7 +792,7 @@ __global__ void __launch_bounds__(256) k_stem(StemArgs a, const __half *__restri
             const int c = row / 17, r = row - c * 17;
             const int iy = iy0 + r, x0 = x00 + cx * 8;
             pv[k] = u4{0u, 0u, 0u, 0u};
-            if (!(a.dbg & 1) && q < 510 && (unsigned)iy < (unsigned)a.H && (unsigned)x0 < (unsigned)a.W)
+            if (!RVA_DBG(a, 1) && q < 510 && (unsigned)iy < (unsigned)a.H && (unsigned)x0 < (unsigned)a.W)
                 pv[k] = *reinterpret_cast<const u4 *>(a.in + ((size_t)(bb * 3 + c) * a.H + iy) * a.W + x0);
         }
     };
@@ -873,7 +882,7 @@ __global__ void __launch_bounds__(256) k_stem(StemArgs a, const __half *__restri
         for (int q = tid; q < 256 * cpr; q += 256) {
             const int px = q / cpr, pc = q - px * cpr;
             const int ox = ox0 + (px & 31), oy = oy0 + (px >> 5);
-            if (ox < a.Wo && oy < a.Ho && !(a.dbg & 4))
+            if (ox < a.Wo && oy < a.Ho && !RVA_DBG(a, 4))
                 *reinterpret_cast<uint4 *>(a.out + ((size_t)(b * a.Ho + oy) * a.Wo + ox) * a.ldo + pc * 8) =
                     *reinterpret_cast<const uint4 *>(stage + (size_t)px * srow + pc * 8);
         }
@@ -2893,13 +2902,10 @@ int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *wei
         ResArgs ra{};
         ra.in = a.in; ra.ldi = ldi; ra.w = a.w; ra.bias = bias; ra.out = a.out; ra.ldo = ldo; ra.res = a.res; ra.ldr = ldr;
         ra.H = H; ra.W = W; ra.Cin = Cin; ra.CinPad = a.CinPad; ra.Cout = Cout; ra.act = act; ra.M = a.M;
-        static int dbg = -1, force_bn = 0;
-        if (dbg < 0) {
-            const char *e = getenv("RVA_CONV_DBG"); dbg = e ? atoi(e) : 0;
-            const char *f = getenv("RVA_CONV_BN"); force_bn = f ? atoi(f) : 0;
-        }
-        ra.dbg = dbg;
-        const bool bn128 = force_bn == 64 ? false : (cpad % 128 == 0);
+#ifdef RVA_ROW_STAMPS
+        { const char *e = getenv("RVA_CONV_DBG"); ra.dbg = e ? atoi(e) : 0; }
+#endif
+        const bool bn128 = cpad % 128 == 0;
         hipError_t e2 = hipErrorInvalidValue;
         if (ksize == 3) {
             // tile = 256 px x 128 ch when that yields enough tiles for every CU, else smaller tiles
@@ -3009,8 +3015,10 @@ int rva_stem_conv_f16(rva_ctx *ctx, const void *in_planar, const void *weights, 
 {
     if (!ctx || !in_planar || !weights || !bias || !out || Cout % 8 || Cout > 64 || ldo % 8)
         return rva_fail(ctx, RVA_ERR_ARG, "rva_stem_conv_f16: bad argument");
-    StemArgs a{(const __half *)in_planar, nullptr, bias, (__half *)out, batch, H, W, (H - 1) / 2 + 1, (W - 1) / 2 + 1, Cout, ldo, 0};
+    StemArgs a{(const __half *)in_planar, nullptr, bias, (__half *)out, batch, H, W, (H - 1) / 2 + 1, (W - 1) / 2 + 1, Cout, ldo};
+#ifdef RVA_ROW_STAMPS
     { const char *e = getenv("RVA_STEM_DBG"); a.dbg = e ? atoi(e) : 0; }
+#endif
     const int total_tiles = rva_ceil_div(a.Wo, 32) * rva_ceil_div(a.Ho, 8) * batch;
     int grid = 256 * 4;                                     // persistent: ~4 blocks per CU (LDS-limited)
     if (grid > total_tiles) grid = total_tiles;

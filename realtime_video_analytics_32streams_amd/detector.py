@@ -94,13 +94,12 @@ class HipYoloDetector(BaseDetector):
     """
 
     def __init__(self, config: DetectorConfig, infer_fn=None, net: Optional[torch.nn.Module] = None,
-                 seed: int = 0, device: Optional[int] = None, engine: str = "fused"):
-        """``engine``: ``"fused"`` runs the network as the librva plan (one MFMA launch per layer, fp16 only);
-        ``"torch"`` runs the torch module through MIOpen (also the fp32 path)."""
+                 seed: int = 0, device: Optional[int] = None):
+        """``half: true`` (every BASELINE configuration) runs the network as the librva plan: hand-written MFMA kernels, one
+        launch per layer, fp16 operands with fp32 accumulation.  ``half: false`` is the reference's fp32 precision
+        (detector.py:248-251): there is no hand-written fp32 plan, the module then runs through PyTorch-ROCm (MIOpen) and
+        the constructor says so in the log -- a configuration never changes engines silently."""
         super().__init__(config)
-        if engine not in ("fused", "torch"):
-            raise ValueError("engine must be 'fused' or 'torch'")
-        self.engine = engine
         self._plans = {}
         self.ctx = ops.context(device)            # raises RuntimeError when no HIP device (no CPU fallback)
         self.device = torch.device("cuda", self.ctx.device)
@@ -109,6 +108,7 @@ class HipYoloDetector(BaseDetector):
         else:
             self.input_hw = (640, 640)            # detector.py:582-583 default
         self.half = bool(config.half)
+        self.engine = "fused" if self.half else "torch-fp32"
         self._infer_fn = infer_fn
         self.net = None
         if infer_fn is None:
@@ -117,6 +117,9 @@ class HipYoloDetector(BaseDetector):
                 net = build_detector_net(scale, seed=seed, weights=config.model_path)
                 LOGGER.info("hip detector: YOLOv8%s, %s weights", scale,
                             "local state-dict" if _is_file(config.model_path) else "seeded random (no weights offline)")
+            if not self.half:
+                LOGGER.warning("hip detector: half=false -> fp32 network through PyTorch-ROCm (MIOpen); the hand-written fp16 "
+                               "MFMA plan runs with `half: true`")
             net = net.fuse().to(self.device)
             net = net.half() if self.half else net.float()
             self.net = net.to(memory_format=torch.channels_last)
@@ -180,10 +183,11 @@ class HipYoloDetector(BaseDetector):
     def _infer(self, tensor: torch.Tensor) -> torch.Tensor:
         if self._infer_fn is not None:
             return self._infer_fn(tensor)
-        if self.engine == "fused" and self.half and tensor.dtype == torch.float16:
-            plan = self.plan_for(tensor)
-            return plan(tensor.contiguous())
-        return self.net(tensor.contiguous(memory_format=torch.channels_last))
+        if self.half:
+            if tensor.dtype != torch.float16:
+                raise TypeError("half detector: the fused plan takes the fp16 tensor K1 writes")
+            return self.plan_for(tensor)(tensor.contiguous())
+        return self.net(tensor.float().contiguous(memory_format=torch.channels_last))
 
     def _postprocess_device(self, raw: torch.Tensor, metas: Sequence[N.Letterbox]) -> ops.PostBuffers:
         raw = raw.contiguous()

@@ -30,6 +30,25 @@ def _p(t: torch.Tensor) -> C.c_void_p:
     return C.c_void_p(t.data_ptr())
 
 
+_LIB_DIGEST: Optional[str] = None
+
+
+def _lib_digest() -> str:
+    """sha256 of librva.so: a rebuilt library never inherits another build's kernel selection."""
+    global _LIB_DIGEST
+    if _LIB_DIGEST is None:
+        import hashlib
+        _LIB_DIGEST = hashlib.sha256(N.LIB_PATH.read_bytes()).hexdigest()
+    return _LIB_DIGEST
+
+
+def _tuning_dir():
+    import os
+    from pathlib import Path
+    d = os.environ.get("RVA_TUNE_CACHE_DIR")
+    return Path(d) if d else Path(os.environ.get("XDG_CACHE_HOME", str(Path.home() / ".cache"))) / "rva_amd" / "autotune"
+
+
 class _View:
     """A channel slice of an NHWC buffer: (tensor [M, ld], channel offset, channels)."""
 
@@ -360,15 +379,65 @@ class FusedYoloV8:
         self._steps.append(head)
 
     # -- per-layer kernel selection ---------------------------------------------------------------------
+    # -- persisted kernel selection -----------------------------------------------------------------------
+    def _tuning_key(self) -> str:
+        """What a kernel selection depends on: the device, the library build, the layer shapes of the plan (batch included)
+        and the switches that change how the selection is made."""
+        import hashlib
+        import os
+        h = hashlib.sha256()
+        h.update(torch.cuda.get_device_name(self.dev).encode())
+        h.update(_lib_digest().encode())
+        h.update(repr((self.B, self.H, self.W, [d for _, _, d in self._tunable])).encode())
+        h.update(repr([os.environ.get(k, "") for k in ("RVA_SKIP_VARIANTS", "RVA_TUNE_IN_PLAN", "RVA_TUNE_OVERLAP", "RVA_TUNE_TOP",
+                                                       "RVA_TUNE_WITHIN", "RVA_NO_STEM2", "RVA_HEAD_SPLIT")]).encode())
+        return h.hexdigest()[:24]
+
+    def _load_tuning(self) -> bool:
+        import json
+        f = _tuning_dir() / f"{self._tuning_key()}.json"
+        try:
+            rec = json.loads(f.read_text())
+            picks = rec["variants"]
+            if len(picks) != len(self._tunable) or any(d != pd for (_, _, d), (pd, _) in zip(self._tunable, picks)):
+                return False
+        except (OSError, ValueError, KeyError, TypeError):
+            return False
+        for (_, state, _), (_, v) in zip(self._tunable, picks):
+            state["variant"] = int(v)
+        self.tuning = [tuple(t) for t in rec.get("tuning", [])]
+        self.tuning_source = str(f)
+        return True
+
+    def _store_tuning(self) -> None:
+        import json
+        import os
+        d = _tuning_dir()
+        try:
+            d.mkdir(parents=True, exist_ok=True)
+            tmp = d / f".{self._tuning_key()}.{os.getpid()}.tmp"
+            tmp.write_text(json.dumps({"device": torch.cuda.get_device_name(self.dev), "batch": self.B, "hw": [self.H, self.W],
+                                       "variants": [[desc, st["variant"]] for _, st, desc in self._tunable],
+                                       "tuning": [list(t) for t in self.tuning]}))
+            os.replace(tmp, d / f"{self._tuning_key()}.json")            # atomic: concurrent ranks write the same content
+        except OSError:
+            pass                                                        # a read-only cache directory costs start-up time only
+
     def autotune(self, reps: int = 5) -> None:
         """Time every applicable conv kernel variant on each layer's real shape (buffers hold whatever they
         hold: timing only) and keep the fastest.  All variants compute the same sums in fp32 with the same
-        per-chunk order of K, so the choice does not change results beyond fp32 summation order."""
+        per-chunk order of K, so the choice does not change results beyond fp32 summation order.  The selection is
+        persisted per (device, library build, plan shape): a later process takes it over instead of timing again
+        (``RVA_TUNE_CACHE=0`` disables, ``RVA_TUNE_CACHE_DIR`` moves it)."""
+        import os
+        self.tuning_source = "measured"
+        use_cache = os.environ.get("RVA_TUNE_CACHE", "1") == "1"
+        if use_cache and self._load_tuning():
+            return
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         self.tuning = []
         self._candidates = {}
         self._n_variants = int(N.lib().rva_conv_num_variants())
-        import os
         skip = {int(v) for v in os.environ.get("RVA_SKIP_VARIANTS", "").replace(",", " ").split()}      # tuning aid: same-box A/B of kernel families
         cache = {}
         for launch, state, desc in self._tunable:
@@ -397,6 +466,8 @@ class FusedYoloV8:
             self.tuning.append((desc, best[0], round(best[1], 1)))
         if os.environ.get("RVA_TUNE_IN_PLAN", "1") == "1":
             self._refine_in_plan()
+        if use_cache:
+            self._store_tuning()
 
     def copy_tuning(self, other: "FusedYoloV8") -> None:
         """Take over the kernel selection of a plan built from the same network and batch shape."""

@@ -356,15 +356,25 @@ class TickPipeline:
 class PipelinedTicks:
     """Throughput mode of :class:`TickPipeline`: ``depth`` ticks in flight, no host round trip inside a tick.
 
-    Two HIP streams with fixed roles.  Stream A: roi / downsample / K5 motion counts (eager), then per frame group K1
-    (eager) + the detector network; stream B: per group K2/K3 -> K4 (gates decided on the device), then global ids -> D2H
-    snapshot of the track tables (slot = tick parity).  With ``use_graph`` the networks and the part on B are replayed
-    from captured hipGraphs (one per head-tensor parity; the fused plan never allocates or synchronises).  A tick shape
-    (which streams are live, their grouping) is captured after it has run eagerly once -- that eager tick sizes every
-    buffer and sets every kernel attribute outside any capture -- and ticks of another shape run eagerly.  With sharded
-    streams (``pipe.id_sync``) the RCCL exchange of new-track counts, ``k4_assign_ids`` and the snapshot follow B's graph
-    eagerly.  B's work for tick k is released once the first K1 of tick k+1 is through, so the latency-bound tail hides
-    under the next network and K1 runs alone.  Same results as ``TickPipeline.tick`` (same kernels, same order per
+    Default layout (``depth=2``, ``net_streams=2``): a tick is ONE chain on one HIP stream --
+
+        roi / downsample / K5 motion counts -> per frame group K1 -> detector network (launched eagerly) ->
+        K2/K3 -> K4 (gates decided on the device) -> global ids -> D2H snapshot (slot = tick parity)
+
+    -- and consecutive ticks alternate between two streams, so the forward pass of tick k+1 (stem, 160x160 / 80x80
+    layers) fills the CUs the tail of tick k's pass (20x20 layers, detect branches) leaves idle.  Each parity owns an input
+    tensor, a fused plan (activation buffers), a head tensor and a snapshot slot.  What orders the two chains, by events:
+    K1(k) after K1(k-1) (gate state, source rings); network(k) after the tail of tick k-2 (head tensor and snapshot slot
+    of this parity); tail(k) after tail(k-1) (tracker tables and the shared K2/K3 scratch are touched in tick order);
+    ``collect(k)`` on the tail's event.  With ``use_graph`` the tail (K2/K3 -> K4 [-> ids -> snapshot]) is replayed from a
+    hipGraph captured per parity; a tick shape (which streams are live, their grouping) is captured after it has run
+    eagerly once -- that tick sizes every buffer and sets every kernel attribute outside any capture -- and ticks of
+    another shape run eagerly.  With sharded streams (``pipe.id_sync``) the exchange of new-track counts (RCCL),
+    ``k4_assign_ids`` and the snapshot follow the graph eagerly on the same stream.
+
+    ``net_streams=1`` (or ``RVA_NET_STREAMS=1``) is the older layout: stream A carries K1 + the network with the detect
+    branches forked onto side streams, stream B the tails, released once the next tick's K1 is through.  ``depth=1`` runs
+    strictly one tick at a time.  Same results as ``TickPipeline.tick`` in every layout (same kernels, same order per
     stream).  Detectors without a batched device path need the host in the loop and are not supported here.
 
     ``submit()`` enqueues one tick and returns its ticket; ``collect()`` returns ``(ticket, tables)`` of the oldest

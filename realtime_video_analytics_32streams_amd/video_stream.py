@@ -48,24 +48,44 @@ class FramePacket:
     timestamp: float
 
 
+@dataclass
+class _Misses:
+    """Failed reads of a capture loop.  ``run`` counts them since the last delivered frame and is what ``max_retries``
+    is held against (a reopen does not clear it, video_stream.py:177,187); ``streak`` counts them since the last frame
+    OR the last successful reopen and sizes the back-off / triggers the reopen (:178,203-206,213-220)."""
+
+    run: int = 0
+    streak: int = 0
+
+    def frame(self) -> None:
+        self.run = self.streak = 0
+
+    def miss(self) -> None:
+        self.run += 1
+        self.streak += 1
+
+    def pause(self, base: float) -> float:
+        return min(base * (1 + 0.5 * self.streak), 30.0)
+
+
 class _BaseStream:
     """Capture plugin surface of the reference's ``VideoStream`` (video_stream.py:47-243) over a device-frame source.
 
     Subclasses supply three synchronous primitives -- ``open_sync()`` (raise ``RuntimeError`` when the source cannot be
     opened, like video_stream.py:78-79), ``next_surface()`` (one frame, ``None`` = the read failed) and ``close_sync()`` --
-    and inherit the reference's behaviour around them: frame ids restart at 0 on every (re)open (:85), a failed read
-    backs off ``min(reconnect_backoff * (1 + 0.5 * consecutive_failures), 30)`` seconds (:203-206), the third consecutive
-    failure closes and reopens the source (:213-224; a failed reopen leaves the stream closed and the loop sleeping
+    and inherit the reference's policy around them: frame ids restart at 0 on every (re)open (:85), a failed read
+    backs off ``min(reconnect_backoff * (1 + 0.5 * streak), 30)`` seconds (:203-206), the third failure in a streak closes
+    and reopens the source (:213-224; a failed reopen leaves the stream closed and the loop idling one
     ``reconnect_backoff`` per turn, :169-171), ``max_retries`` failed reads in a row end the generator (:187-197), and
-    pacing sleeps ``1 / target_fps`` AFTER the consumer has taken the frame (:242-243).  Pinned by
-    tests/golden/capture_loop.json, recorded from the reference's own ``frames()``."""
+    pacing sleeps ``1 / target_fps`` AFTER the consumer has taken the frame (:242-243).  The observable sequence (opens,
+    closes, every sleep, frame ids) is pinned by tests/golden/capture_loop.json, recorded from the reference's own
+    ``frames()``."""
 
     def __init__(self, stream_config: StreamConfig):
         self.config = stream_config
         self._frame_id = 0
         self._opened = False
-        self._consecutive_failures = 0
-        self._last_successful_read = time.time()
+        self._misses = _Misses()
         self._sleep = asyncio.sleep          # the one suspension point besides the read: injectable for tests
 
     async def __aenter__(self):
@@ -79,8 +99,7 @@ class _BaseStream:
         if self._opened:
             return
         self.open_sync()
-        self._consecutive_failures = 0
-        self._last_successful_read = time.time()
+        self._misses.streak = 0
         if self.config.warmup_seconds > 0:
             await self._sleep(self.config.warmup_seconds)
 
@@ -98,53 +117,53 @@ class _BaseStream:
     def next_surface(self) -> Optional[Nv12Surface]:
         raise NotImplementedError
 
+    def _packet(self, surface) -> FramePacket:
+        pkt = FramePacket(stream=self.config, frame=surface, frame_id=self._frame_id, timestamp=time.time())
+        self._frame_id += 1
+        return pkt
+
     def next_packet(self) -> Optional[FramePacket]:
         """Synchronous pull used by the batched tick loop (no retry policy: ``None`` masks the stream out of the tick)."""
         if not self._opened:
             self.open_sync()
         surf = self.next_surface()
-        if surf is None:
-            return None
-        pkt = FramePacket(stream=self.config, frame=surf, frame_id=self._frame_id, timestamp=time.time())
-        self._frame_id += 1
-        return pkt
+        return None if surf is None else self._packet(surf)
+
+    async def _reopen(self) -> None:
+        """Close and open again; a source that does not come back stays closed (the loop then idles until it does)."""
+        LOGGER.info("stream '%s': %d reads failed in a row, reopening the source", self.config.name, self._misses.streak)
+        await self.close()
+        try:
+            await self.open()
+        except Exception as exc:  # noqa: BLE001
+            LOGGER.error("stream '%s': reopen failed (%s)", self.config.name, exc)
 
     async def frames(self) -> AsyncGenerator[FramePacket, None]:
+        cfg = self.config
         if not self._opened:
             await self.open()
-        retry_count = 0
+        misses = self._misses = _Misses()
+        gap = max(0.0, 1.0 / cfg.target_fps) if cfg.target_fps else None
         while True:
-            if not self._opened:
-                await self._sleep(self.config.reconnect_backoff)
+            if not self._opened:                      # the last reopen failed
+                await self._sleep(cfg.reconnect_backoff)
                 continue
-            surf = await asyncio.to_thread(self.next_surface)
-            if surf is None:
-                retry_count += 1
-                self._consecutive_failures += 1
-                LOGGER.warning("Failed to read frame from '%s' (retry=%d, consecutive_failures=%d)", self.config.name,
-                               retry_count, self._consecutive_failures)
-                if self.config.max_retries is not None and retry_count >= self.config.max_retries:
-                    LOGGER.error("Giving up on stream '%s' after %d retries", self.config.name, retry_count)
-                    break
-                backoff_time = min(self.config.reconnect_backoff * (1 + self._consecutive_failures * 0.5), 30.0)
-                if self._consecutive_failures >= 3:
-                    LOGGER.info("Attempting to reconnect stream '%s'", self.config.name)
-                    await self.close()
-                    try:
-                        await self.open()
-                        self._consecutive_failures = 0
-                    except Exception as exc:  # noqa: BLE001
-                        LOGGER.error("Failed to reconnect stream '%s': %s", self.config.name, exc)
-                await self._sleep(backoff_time)
+            surface = await asyncio.to_thread(self.next_surface)
+            if surface is not None:
+                misses.frame()
+                yield self._packet(surface)
+                if gap is not None:
+                    await self._sleep(gap)            # pacing comes after the consumer has had the frame
                 continue
-            retry_count = 0
-            self._consecutive_failures = 0
-            self._last_successful_read = time.time()
-            pkt = FramePacket(stream=self.config, frame=surf, frame_id=self._frame_id, timestamp=time.time())
-            self._frame_id += 1
-            yield pkt
-            if self.config.target_fps:
-                await self._sleep(max(0.0, 1.0 / self.config.target_fps))
+            misses.miss()
+            LOGGER.warning("stream '%s': no frame (%d in a row, %d since the last reopen)", cfg.name, misses.run, misses.streak)
+            if cfg.max_retries is not None and misses.run >= cfg.max_retries:
+                LOGGER.error("stream '%s': %d reads failed in a row, giving up", cfg.name, misses.run)
+                return
+            pause = misses.pause(cfg.reconnect_backoff)     # sized before a successful reopen clears the streak
+            if misses.streak >= 3:
+                await self._reopen()
+            await self._sleep(pause)
 
 
 class SyntheticNv12Stream(_BaseStream):
