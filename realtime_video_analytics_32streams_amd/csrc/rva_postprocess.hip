@@ -14,6 +14,13 @@
 //       sorted boxes among themselves with ballots/shuffles, then every thread clears later boxes
 //       against the chunk's survivors.  Same keep set as the reference's sequential loop because
 //       greedy NMS is order-determined.  `keep` indices are recovered from the bitmap by popcount.
+//   K3 under load (more than K3_SMALL = 128 and at most 4096 sorted candidates in an image): the chunk loop above is
+//       serial per image (~10 us per 64 candidates).  Such an image leaves k3_nms after the sort; k3_mask computes its
+//       whole suppression matrix on all CUs -- one wave per 64 x 64 tile of (higher-priority box i, box j > i), the same
+//       float32 IoU and the same `!(iou <= thr)` test, one ballot per row -> bit j of word j/64 of row i -- and
+//       k3_reduce replays the greedy loop over that matrix with one wave per image: a 64-bit scalar walk inside a
+//       chunk (next alive box, clear what its diagonal word suppresses), then the kept rows are OR-ed into the
+//       per-chunk "removed" words the lanes hold.  Order-determined like the loop it replaces: identical keep set.
 #include <hip/hip_fp16.h>
 
 #include "rva_internal.h"
@@ -128,9 +135,15 @@ struct K3Args {
     float *out_scores;
     int32_t *out_cls, *out_anchor, *out_cand, *out_counts, *out_ncand;
     int32_t *flags;
+    // hand-off to the suppression-bitmask path (null m_mask: every image finishes here)
+    int km;
+    int32_t *m_state, *m_anchor, *m_wprefix;
+    float4 *m_box;
+    unsigned long long *m_mask;
 };
 
 constexpr int K3_THREADS = 512;
+constexpr int K3_SMALL = 128;      // up to two 64-box chunks an image finishes inside k3_nms (cheaper than two more launches' work)
 
 extern __shared__ __attribute__((aligned(16))) unsigned char k3_smem[];
 
@@ -151,7 +164,7 @@ __global__ void __launch_bounds__(K3_THREADS) k3_nms(K3Args a)
         K = a.kcap;
     }
     if (K == 0) {
-        if (tid == 0) a.out_counts[b] = 0;
+        if (tid == 0) { a.out_counts[b] = 0; if (a.m_state) a.m_state[b] = 0; }
         return;
     }
     int Kpad = 64;
@@ -233,6 +246,19 @@ __global__ void __launch_bounds__(K3_THREADS) k3_nms(K3Args a)
             }
         }
     }
+    // busy image: hand the sorted candidates to k3_mask / k3_reduce (all CUs build the suppression matrix)
+    const bool hand = a.m_mask != nullptr && K > K3_SMALL && K <= a.km;
+    if (a.m_state && tid == 0) a.m_state[b] = hand ? K : 0;
+    if (hand) {
+        for (int i = tid; i < K; i += K3_THREADS) {
+            const int an = (int)(uint32_t)keys[i];
+            a.m_anchor[(size_t)b * a.km + i] = an;
+            a.m_box[(size_t)b * a.km + i] = box[an];
+        }
+        if (a.out_cand)
+            for (int w = tid; w < a.nwords; w += K3_THREADS) a.m_wprefix[(size_t)b * a.nwords + w] = wprefix[w];
+        return;
+    }
     const int nchunks = (K + 63) >> 6;
     for (int c = 0; c < nchunks; ++c) {
         const int base = c << 6;
@@ -289,6 +315,104 @@ __global__ void __launch_bounds__(K3_THREADS) k3_nms(K3Args a)
         const int n = s_ctl[1];
         a.out_counts[b] = n < a.max_det ? n : a.max_det;
     }
+}
+
+__device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int l)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// Suppression matrix of the images k3_nms handed over.  grid = (K3M_BX, images), 4 waves per block, a wave per 64 x 64 tile
+// (row tile ti = the suppressing boxes, column tile tj >= ti), tiles dealt round-robin over the image's waves.
+constexpr int K3M_BX = 32;
+
+__global__ void __launch_bounds__(256) k3_mask(K3Args a)
+{
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const int K = a.m_state[b];
+    if (K == 0) return;
+    const int nt = (K + 63) >> 6, kmw = a.km >> 6;
+    const float4 *mb = a.m_box + (size_t)b * a.km;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = blockIdx.x * 4 + (threadIdx.x >> 6); t < nt * nt; t += K3M_BX * 4) {
+        const int ti = t / nt, tj = t - ti * nt;
+        if (tj < ti) continue;
+        const int col = tj * 64 + lane, row0 = ti * 64;
+        const float4 cb = col < K ? mb[col] : zero;
+        const float4 rb = row0 + lane < K ? mb[row0 + lane] : zero;
+        const int nrow = K - row0 < 64 ? K - row0 : 64;
+        unsigned long long mine = 0ull;
+        for (int i = 0; i < nrow; ++i) {                       // i is wave-uniform: the row box travels through scalar registers
+            float4 kb;
+            kb.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rb.x), i));
+            kb.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rb.y), i));
+            kb.z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rb.z), i));
+            kb.w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rb.w), i));
+            const bool sup = col < K && col > row0 + i && !(iou32(kb, cb) <= a.iou_thr);     // detector.py:373, a = the kept box
+            const unsigned long long w = __ballot(sup);
+            if (lane == i) mine = w;
+        }
+        if (row0 + lane < K) a.m_mask[((size_t)b * a.km + row0 + lane) * kmw + tj] = mine;
+    }
+}
+
+// Greedy pass over the suppression matrix: one wave per image, lane w keeps the "removed" word of chunk w.
+__global__ void __launch_bounds__(64) k3_reduce(K3Args a)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int K = a.m_state[b];
+    if (K == 0) return;
+    const int nt = (K + 63) >> 6, kmw = a.km >> 6;
+    const unsigned long long *mm = a.m_mask + (size_t)b * a.km * kmw;
+    unsigned long long removed = 0ull;
+    int out = 0;
+    for (int c = 0; c < nt; ++c) {
+        const int base = c << 6, i = base + lane;
+        const unsigned long long diag = i < K ? mm[(size_t)i * kmw + c] : 0ull;
+        const unsigned long long rem = readlane64(removed, c);
+        const unsigned long long vm = K - base >= 64 ? ~0ull : ((1ull << (K - base)) - 1ull);
+        unsigned long long alive = ~rem & vm, kept = 0ull;
+        while (alive) {                                           // scalar walk: next alive box survives and clears its victims
+            const int l = __builtin_ctzll(alive);
+            kept |= 1ull << l;
+            alive &= ~readlane64(diag, l);
+            alive &= ~(1ull << l);
+        }
+        // the survivors' rows suppress boxes of later chunks: OR them into the removed words (four loads in flight)
+        const bool later = lane > c && lane < nt;
+        unsigned long long k2 = kept;
+        while (k2) {
+            int l[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { l[q] = k2 ? __builtin_ctzll(k2) : -1; if (k2) k2 &= k2 - 1ull; }
+            unsigned long long r[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) r[q] = (l[q] >= 0 && later) ? mm[(size_t)(base + l[q]) * kmw + lane] : 0ull;
+            removed |= r[0] | r[1] | r[2] | r[3];
+        }
+        if ((kept >> lane) & 1ull) {
+            const int pos = out + __popcll(kept & ((1ull << lane) - 1ull));
+            if (pos < a.max_det) {
+                const int an = a.m_anchor[(size_t)b * a.km + i];
+                const long o = (long)b * a.max_det + pos;
+                a.out_boxes[o] = a.m_box[(size_t)b * a.km + i];
+                a.out_scores[o] = a.sp_score[(long)b * a.A + an];
+                a.out_cls[o] = a.sp_cls[(long)b * a.A + an];
+                if (a.out_anchor) a.out_anchor[o] = an;
+                if (a.out_cand) {
+                    const int w = an >> 5;
+                    a.out_cand[o] = a.m_wprefix[(size_t)b * a.nwords + w] +
+                                    __popc(a.bits[(long)b * a.nwords + w] & ((1u << (an & 31)) - 1u));
+                }
+            } else {
+                atomicOr(a.flags, 1);
+            }
+        }
+        out += __popcll(kept);
+    }
+    if (lane == 0) a.out_counts[b] = out < a.max_det ? out : a.max_det;
 }
 
 __global__ void k_zero_counts(int32_t *p, int n)
@@ -369,7 +493,12 @@ extern "C" int rva_postprocess_batch(rva_ctx *ctx, const void *raw, int raw_dtyp
         k3.out_counts = out_counts + b0;
         k3.out_ncand = out_ncand ? out_ncand + b0 : nullptr;
         k3.flags = ctx->post_flags;
+        k3.km = ctx->k3_km; k3.m_state = ctx->k3_state; k3.m_anchor = ctx->k3_anchor; k3.m_box = (float4 *)ctx->k3_box;
+        k3.m_mask = ctx->k3_mask; k3.m_wprefix = ctx->k3_wprefix;
         k3_nms<<<nb, K3_THREADS, smem, stream>>>(k3);
+        // busy images (k3_state[b] > 0) continue here; for the others both launches return at once
+        k3_mask<<<dim3(K3M_BX, nb), 256, 0, stream>>>(k3);
+        k3_reduce<<<nb, 64, 0, stream>>>(k3);
     }
     RVA_HIP(ctx, hipGetLastError());
     return RVA_OK;

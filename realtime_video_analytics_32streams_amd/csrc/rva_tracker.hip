@@ -13,6 +13,18 @@
 // New tracks get provisional ids -(k+1); k4_assign_ids turns them into the reference's global
 // counter values in canonical order (tick-major, stream-minor), using the new-track counts of ALL
 // streams of the job (all-gathered over RCCL when streams are sharded across GPUs).
+//
+// Under load (float32 source = the post-process output, up to `dm` detections per frame) the float64 IoUs leave the
+// serial loop ("K4 matrix on GPU, sequential assign per stream"):
+//   k4_iou     all CUs: row d of a per-stream matrix V holds the IoU of detection d with every track the frame started
+//              with (columns 0..T0) and with every earlier detection of the frame (columns T0r + d'), class mismatch
+//              stored as 0.0 (the reference skips such tracks, and a 0.0 can never win `iou > best`, best >= 0).  Same
+//              iou64(), same argument order, -ffp-contract=off: the values the serial scan would have computed, because
+//              a row's box at any point of the frame is either its old box or the box of the last detection matched to it.
+//   k4_update  one wave per stream: per row a register holds which column of V currently stands for the row (itself,
+//              or T0r + last matching detection); a detection gathers its row of V from an LDS ring (filled 4-16 rows
+//              ahead by LDS-DMA), takes the maximum with the earliest row on ties, and repoints one register.  No
+//              float64 arithmetic and no global memory access inside the loop.
 #include <climits>
 #include <cstring>
 
@@ -41,6 +53,8 @@ struct rva_tracker {
     int32_t *d_offs = nullptr;    // [S+1]
     int32_t *d_gidx = nullptr;    // [S]
     double *d_bscale = nullptr;   // [S] box scale of _rescale_detections (1.0 = no downsample)
+    double *d_V = nullptr;        // [S][dm][ld] IoU matrix of the tick (k4_iou -> k4_update), null: always the in-loop form
+    int dm = 0, ld = 0;           // detections per frame the matrix holds; row stride in doubles (multiple of 128)
     // pre-detector gates decided on the device (pipeline.py:156-170, 242-262), see rva_tracker_set_gates
     int32_t *gate_cfg = nullptr;    // [S][4] adaptive enabled, max_process_every, idle_tolerance, motion minimum count
     int32_t *gate_state = nullptr;  // [S][4] frame_index, idle_frames, process_every, -
@@ -75,7 +89,37 @@ struct K4Args {
     double filter_thr;
     // f64 source (host API)
     const int32_t *offs; const double *boxes64; const double *conf64; const int64_t *cls64;
+    // IoU matrix path (f32 source only)
+    double *V; int dm, ld;
 };
+
+constexpr int K4_RMAX = 16;            // matrix path: 64 * 16 rows per stream at most (capacity <= 1024)
+constexpr int K4_RING_BYTES = 96 * 1024;
+
+__device__ __forceinline__ int k4_round128(int v) { return (v + 127) & ~127; }
+inline int k4_round128_host(int v) { return (v + 127) & ~127; }
+
+// Pre-detector gates decided on the device (f32 path): motion gate first (utils/frame_filter.py:26-40 via the K5 count,
+// first frame always passes), then the adaptive-fps gate (pipeline.py:165-170).  Reads the state the previous tick left.
+struct K4Gate { bool process; int fi, idle, pe, on, maxpe, tol; };
+
+__device__ __forceinline__ K4Gate k4_gate(const K4Args &a, int s, int slot)
+{
+    K4Gate g{slot >= 0, 0, 0, 1, 0, 1, 0};
+    if (a.gate_cfg) {
+        const int32_t *cfg = a.gate_cfg + 4 * s;
+        const int32_t *st = a.gate_state + 4 * s;
+        g.on = cfg[0]; g.maxpe = cfg[1]; g.tol = cfg[2];
+        g.fi = st[0] + 1; g.idle = st[1]; g.pe = st[2];            // pipeline.py:144: the frame index advances for every frame
+        const int mr = a.mrow[s];
+        if (mr >= 0) {
+            const int cnt = a.motion_cnt[mr];
+            if (cnt >= 0 && cnt < cfg[3]) g.process = false;       // ratio < motion_threshold (host turned it into a count)
+        }
+        if (g.on && g.pe > 1 && (g.fi - 1) % g.pe != 0) g.process = false;
+    }
+    return g;
+}
 
 // tracker.py:129-147, float64; a = track, b = detection
 __device__ __forceinline__ double iou64(const double a0, const double a1, const double a2, const double a3,
@@ -96,7 +140,101 @@ __device__ __forceinline__ double iou64(const double a0, const double a1, const 
     return __ddiv_rn(inter, uni);
 }
 
+__device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int l)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ double readlane_f64(double v, int l) { return __longlong_as_double((long long)readlane_u64((unsigned long long)__double_as_longlong(v), l)); }
+
 extern __shared__ __attribute__((aligned(16))) unsigned char k4_smem[];
+
+// a detection of the float32 source as the tracker sees it: exact widening, then _rescale_detections (float64 multiply)
+__device__ __forceinline__ void k4_det_box(const K4Args &a, size_t o, double bs, double &b0, double &b1, double &b2, double &b3)
+{
+    const float4 f = a.boxes32[o];
+    b0 = (double)f.x; b1 = (double)f.y; b2 = (double)f.z; b3 = (double)f.w;
+    if (bs != 1.0) { b0 *= bs; b1 *= bs; b2 *= bs; b3 *= bs; }
+}
+
+// ---- IoU matrix of the tick -------------------------------------------------------------------------------------------
+// grid = (K4_IOU_BX, streams), 256 threads.  A block takes tiles of 4 detections (rows of V) and sweeps the columns: the
+// T0 tracks the frame starts with, then the detections before the row's own.  Streams that k4_update will not run the
+// matrix form for (no frame, skipped frame, gated out, more than dm detections) return at once.
+constexpr int K4_IOU_BX = 16;
+
+__global__ void __launch_bounds__(256) k4_iou(K4Args a)
+{
+    const int s = blockIdx.y, tid = threadIdx.x;
+    const int slot = (int)a.kslot[s];
+    if (slot < 0) return;
+    if (!k4_gate(a, s, slot).process) return;
+    const int D = a.counts32[slot];
+    if (D <= 0 || D > a.dm) return;
+    const int T0 = a.n_tracks[s], T0r = k4_round128(T0);
+    const double bs = a.bscale[s];
+    const size_t tb = (size_t)s * a.cap;
+    double *Vs = a.V + (size_t)s * a.dm * a.ld;
+    for (int d0 = blockIdx.x * 4; d0 < D; d0 += K4_IOU_BX * 4) {
+        double db[4][4];
+        int dc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int d = d0 + q < D ? d0 + q : D - 1;
+            const size_t o = (size_t)slot * a.max_det + d;
+            k4_det_box(a, o, bs, db[q][0], db[q][1], db[q][2], db[q][3]);
+            dc[q] = a.cls32[o];
+        }
+        for (int j = tid; j < T0; j += 256) {                  // columns 0..T0: the tracks as the frame finds them
+            const double2 t01 = reinterpret_cast<const double2 *>(a.box)[2 * (tb + j)];
+            const double2 t23 = reinterpret_cast<const double2 *>(a.box)[2 * (tb + j) + 1];
+            const int tc = a.cls[tb + j];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (d0 + q < D)                                  // tracker.py:103-105; a = track, b = detection
+                    Vs[(size_t)(d0 + q) * a.ld + j] = tc == dc[q] ? iou64(t01.x, t01.y, t23.x, t23.y, db[q][0], db[q][1], db[q][2], db[q][3]) : 0.0;
+        }
+        for (int e = tid; e < d0 + 3 && e < D; e += 256) {     // columns T0r + e: a row that detection e (re)wrote earlier in the frame
+            const size_t o = (size_t)slot * a.max_det + e;
+            double e0, e1, e2, e3;
+            k4_det_box(a, o, bs, e0, e1, e2, e3);
+            const int ec = a.cls32[o];                           // a row's class is the class of every detection matched to it
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (d0 + q < D && e < d0 + q)
+                    Vs[(size_t)(d0 + q) * a.ld + T0r + e] = ec == dc[q] ? iou64(e0, e1, e2, e3, db[q][0], db[q][1], db[q][2], db[q][3]) : 0.0;
+        }
+    }
+}
+
+typedef __attribute__((address_space(3))) void *k4_lds_ptr;
+__device__ __forceinline__ unsigned k4_lds_addr(const void *p) { return (unsigned)(size_t)(k4_lds_ptr)p; }
+
+// one 1 KiB LDS-DMA piece: 64 lanes x 16 B from sbase + voff to LDS m0v + 16 * lane (the form rva_conv.hip documents)
+__device__ __forceinline__ void k4_dma16(unsigned voff, const void *sbase, unsigned m0v)
+{
+    const unsigned long long b = (unsigned long long)(size_t)sbase;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    const unsigned long long sb = ((unsigned long long)hi << 32) | lo;
+    const unsigned m0s = __builtin_amdgcn_readfirstlane(m0v);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sb), "s"(m0s) : "memory");
+}
+
+// maximum of a detection's row of V over the live rows: lane l looks at rows l, l + 64, ... (ascending, so `>` keeps the
+// earliest row of a lane on ties); src[r] = the column of V that stands for row l + 64 r
+template <int RN>
+__device__ __forceinline__ void k4_scan_row(const double *row, const int (&src)[K4_RMAX], int lane, int n, double min_iou, double &best, int &bi)
+{
+    double v[RN];
+#pragma unroll
+    for (int r = 0; r < RN; ++r) v[r] = row[src[r]];            // all reads in flight before the first compare
+#pragma unroll
+    for (int r = 0; r < RN; ++r) {
+        const int k = lane + 64 * r;
+        if (k < n && v[r] >= min_iou && v[r] > best) { best = v[r]; bi = k; }   // tracker.py:106
+    }
+}
 
 template <bool F64SRC>
 __global__ void __launch_bounds__(64) k4_update(K4Args a)
@@ -108,23 +246,152 @@ __global__ void __launch_bounds__(64) k4_update(K4Args a)
         if (lane == 0) { a.n_new[s] = 0; a.processed[s] = -1; a.emitted[s] = 0; }
         return;
     }
-    // pre-detector gates on the device (f32 path): motion gate first (utils/frame_filter.py:26-40 via the K5 count, first
-    // frame always passes), then the adaptive-fps gate (pipeline.py:165-170); a frame that fails either is a skipped frame
-    bool process = F64SRC ? true : slot >= 0;
-    int g_fi = 0, g_idle = 0, g_pe = 1, g_on = 0, g_maxpe = 1, g_tol = 0;
-    if (!F64SRC && a.gate_cfg) {
-        const int32_t *cfg = a.gate_cfg + 4 * s;
-        const int32_t *st = a.gate_state + 4 * s;
-        g_on = cfg[0]; g_maxpe = cfg[1]; g_tol = cfg[2];
-        g_fi = st[0] + 1; g_idle = st[1]; g_pe = st[2];            // pipeline.py:144: the frame index advances for every frame
-        const int mr = a.mrow[s];
-        if (mr >= 0) {
-            const int cnt = a.motion_cnt[mr];
-            if (cnt >= 0 && cnt < cfg[3]) process = false;         // ratio < motion_threshold (host turned it into a count)
-        }
-        if (g_on && g_pe > 1 && (g_fi - 1) % g_pe != 0) process = false;
-    }
+    K4Gate g{true, 0, 0, 1, 0, 1, 0};
+    if (!F64SRC) g = k4_gate(a, s, slot);
+    const bool process = g.process;
     const int cap = a.cap;
+    const size_t tb = (size_t)s * cap;
+    int n = a.n_tracks[s];
+    int D = 0, d0 = 0;
+    if (F64SRC) { d0 = a.offs[s]; D = a.offs[s + 1] - d0; }
+    else if (process) D = a.counts32[slot];
+    int created = 0, n_emit = 0, base = 0;
+    bool overflow = false;
+
+    if (!F64SRC && a.V && D <= a.dm) {
+        // ---------------- matrix form: the IoUs are in V (k4_iou), the loop only picks and repoints ----------------------
+        const int T0 = n, T0r = k4_round128(T0);
+        int32_t *l_cnt = (int32_t *)k4_smem;                        // [cap] matches of the frame per row (a new row starts at 1)
+        unsigned char *ring = k4_smem + (((size_t)cap * 4 + 1023) & ~(size_t)1023);
+        const unsigned ring_lds = k4_lds_addr(ring);
+        const int rowb = ((T0r + D) * 8 + 1023) & ~1023;            // bytes of a ring row: whole 1 KiB pieces
+        const int CH = 32 * rowb <= K4_RING_BYTES ? 16 : (16 * rowb <= K4_RING_BYTES ? 8 : 4);   // detections per half of the ring
+        const double *Vs = a.V + (size_t)s * a.dm * a.ld;
+        const size_t ob = (size_t)slot * a.max_det;
+        for (int k = lane; k < cap; k += 64) l_cnt[k] = 0;
+        // filter_detections (pipeline.py:182): detections below the threshold do not exist for the tracker
+        unsigned long long passw = 0ull;                            // lane i: detections 64 i .. 64 i + 63
+        for (int i = 0; i * 64 < D; ++i) {
+            const int d = i * 64 + lane;
+            const unsigned long long m = __ballot(d < D && (double)a.scores32[ob + (d < D ? d : 0)] >= a.filter_thr);
+            if (lane == i) passw = m;
+            n_emit += __popcll(m);
+        }
+        int src[K4_RMAX];
+#pragma unroll
+        for (int r = 0; r < K4_RMAX; ++r) src[r] = lane + 64 * r < T0 ? lane + 64 * r : 0;
+
+        const int nchunks = (D + CH - 1) / CH;
+        // rows [c CH, (c+1) CH) of V -> ring half c & 1: row d needs its first T0r + d columns
+#define K4_ISSUE(c_)                                                                                              \
+        do {                                                                                                      \
+            const int c__ = (c_);                                                                                 \
+            for (int d_ = c__ * CH; d_ < (c__ + 1) * CH && d_ < D; ++d_) {                                        \
+                const int pieces_ = ((T0r + d_) * 8 + 1023) >> 10;                                                \
+                const unsigned dst_ = ring_lds + (unsigned)(((c__ & 1) * CH + (d_ - c__ * CH)) * rowb);           \
+                for (int p_ = 0; p_ < pieces_; ++p_)                                                              \
+                    k4_dma16((unsigned)((size_t)d_ * a.ld * 8 + p_ * 1024 + lane * 16), Vs, dst_ + p_ * 1024);    \
+            }                                                                                                     \
+        } while (0)
+        if (nchunks) K4_ISSUE(0);
+        for (int c = 0; c < nchunks; ++c) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this chunk's rows have landed (issued a chunk ago)
+            if (c + 1 < nchunks) K4_ISSUE(c + 1);                   // the other half was last read a chunk ago
+            const int dend = (c + 1) * CH < D ? (c + 1) * CH : D;
+            for (int d = c * CH; d < dend; ++d) {
+                const unsigned long long pw = readlane_u64(passw, d >> 6);
+                if (!((pw >> (d & 63)) & 1ull)) continue;
+                const double *row = reinterpret_cast<const double *>(ring + (size_t)((c & 1) * CH + (d - c * CH)) * rowb);
+                double best = 0.0;  // tracker.py:100
+                int bi = INT_MAX;
+                const int rn = (n + 63) >> 6;
+                if (rn <= 2) k4_scan_row<2>(row, src, lane, n, a.min_iou, best, bi);
+                else if (rn <= 4) k4_scan_row<4>(row, src, lane, n, a.min_iou, best, bi);
+                else if (rn <= 8) k4_scan_row<8>(row, src, lane, n, a.min_iou, best, bi);
+                else k4_scan_row<K4_RMAX>(row, src, lane, n, a.min_iou, best, bi);
+                unsigned long long m = __ballot(bi != INT_MAX);
+                int hit = -1;
+                if (m) {
+                    // almost always one lane holds a candidate: its row is the answer.  Otherwise walk the candidates.
+                    int l = __builtin_ctzll(m);
+                    hit = __builtin_amdgcn_readlane(bi, l);
+                    m &= m - 1ull;
+                    if (m) {
+                        double bb = readlane_f64(best, l);
+                        while (m) {
+                            l = __builtin_ctzll(m);
+                            m &= m - 1ull;
+                            const double v = readlane_f64(best, l);
+                            const int k = __builtin_amdgcn_readlane(bi, l);
+                            if (v > bb || (v == bb && k < hit)) { bb = v; hit = k; }
+                        }
+                    }
+                }
+                int rowi;
+                if (hit < 0) {  // tracker.py:69-80 new track, appended immediately
+                    if (n >= cap) { overflow = true; continue; }
+                    rowi = n;
+                    if (lane == 0) l_cnt[n] = 1;
+                    ++n; ++created;
+                } else {        // :81-92
+                    rowi = hit;
+                    if (lane == 0) l_cnt[hit] += 1;
+                }
+                const int rr = rowi >> 6, val = T0r + d;
+                const bool own = lane == (rowi & 63);
+                switch (rr) {   // wave-uniform: one predicated move
+#define K4_SET(R) case R: if (own) src[R] = val; break;
+                    K4_SET(0) K4_SET(1) K4_SET(2) K4_SET(3) K4_SET(4) K4_SET(5) K4_SET(6) K4_SET(7)
+                    K4_SET(8) K4_SET(9) K4_SET(10) K4_SET(11) K4_SET(12) K4_SET(13) K4_SET(14) K4_SET(15)
+#undef K4_SET
+                }
+            }
+        }
+#undef K4_ISSUE
+        // every row: its final values (old ones, or those of the last detection matched to it), prune, stable compaction in
+        // place (a group of 64 rows is read whole before any of its rows is written, and only rows <= the group are written)
+        const double bs = a.bscale[s];
+#pragma unroll
+        for (int r = 0; r < K4_RMAX; ++r) {
+            if (r * 64 >= n) break;
+            const int k = lane + 64 * r;
+            const bool valid = k < n, old = valid && k < T0;
+            const bool touched = valid && (k >= T0 || src[r] >= T0r);
+            double b0 = 0, b1 = 0, b2 = 0, b3 = 0, cf = 0;
+            long long id = 0;
+            int cl = 0, ag = 0, hi = 0, match = 0;
+            if (old) {
+                id = a.id[tb + k]; cl = a.cls[tb + k]; ag = a.age[tb + k]; hi = a.hits[tb + k];
+                if (!touched) {
+                    const double2 t01 = reinterpret_cast<const double2 *>(a.box)[2 * (tb + k)];
+                    const double2 t23 = reinterpret_cast<const double2 *>(a.box)[2 * (tb + k) + 1];
+                    b0 = t01.x; b1 = t01.y; b2 = t23.x; b3 = t23.y; cf = a.conf[tb + k];
+                }
+            }
+            bool keep = false;
+            if (touched) {
+                const int dd = src[r] - T0r;
+                k4_det_box(a, ob + dd, bs, b0, b1, b2, b3);
+                cf = (double)a.scores32[ob + dd];
+                if (!old) { id = -(long long)(k - T0 + 1); cl = a.cls32[ob + dd]; }
+                hi += l_cnt[k]; ag = 0; match = dd + 1;
+                keep = true;
+            } else if (valid) {
+                ag += 1;
+                keep = !(ag > a.max_age || hi < a.min_hits);
+            }
+            const unsigned long long m = __ballot(keep);
+            if (keep) {
+                const size_t o = tb + base + __popcll(m & ((1ull << lane) - 1ull));
+                reinterpret_cast<double2 *>(a.box)[2 * o] = make_double2(b0, b1);
+                reinterpret_cast<double2 *>(a.box)[2 * o + 1] = make_double2(b2, b3);
+                a.conf[o] = cf; a.id[o] = id; a.cls[o] = cl; a.age[o] = ag; a.hits[o] = hi;
+                a.last_det[o] = match - 1;
+            }
+            base += __popcll(m);
+        }
+    } else {
+    // ---------------- in-loop form: table staged in LDS, float64 IoU inside the detection loop ------------------------
     double *l_box = (double *)k4_smem;                 // [4][cap]  (component-major: conflict-free)
     double *l_conf = l_box + 4 * (size_t)cap;          // [cap]
     int64_t *l_id = (int64_t *)(l_conf + cap);         // [cap]
@@ -133,8 +400,6 @@ __global__ void __launch_bounds__(64) k4_update(K4Args a)
     int32_t *l_hits = l_age + cap;
     int32_t *l_match = l_hits + cap;
 
-    const size_t tb = (size_t)s * cap;
-    int n = a.n_tracks[s];
     for (int k = lane; k < n; k += 64) {
         const double *gb = a.box + (tb + k) * 4;
         l_box[k] = gb[0]; l_box[cap + k] = gb[1]; l_box[2 * cap + k] = gb[2]; l_box[3 * cap + k] = gb[3];
@@ -147,11 +412,6 @@ __global__ void __launch_bounds__(64) k4_update(K4Args a)
     }
     __syncthreads();
 
-    int D = 0, d0 = 0;
-    if (F64SRC) { d0 = a.offs[s]; D = a.offs[s + 1] - d0; }
-    else if (process) D = a.counts32[slot];
-    int created = 0, n_emit = 0;
-    bool overflow = false;
     for (int d = 0; d < D; ++d) {
         double b0, b1, b2, b3, dconf;
         int dcls;
@@ -162,10 +422,7 @@ __global__ void __launch_bounds__(64) k4_update(K4Args a)
             dcls = (int)a.cls64[d0 + d];
         } else {
             const size_t o = (size_t)slot * a.max_det + d;
-            const float4 f = a.boxes32[o];
-            b0 = (double)f.x; b1 = (double)f.y; b2 = (double)f.z; b3 = (double)f.w;  // exact widening
-            const double bs = a.bscale[s];
-            if (bs != 1.0) { b0 *= bs; b1 *= bs; b2 *= bs; b3 *= bs; }              // _rescale_detections (float64 multiply)
+            k4_det_box(a, o, a.bscale[s], b0, b1, b2, b3);
             dconf = (double)a.scores32[o];
             dcls = a.cls32[o];
             if (!(dconf >= a.filter_thr)) continue;  // filter_detections, pipeline.py:182 (wave-uniform)
@@ -199,7 +456,6 @@ __global__ void __launch_bounds__(64) k4_update(K4Args a)
         __syncthreads();
     }
     // :111-126 prune, stable compaction back to HBM
-    int base = 0;
     for (int k0 = 0; k0 < n; k0 += 64) {
         const int k = k0 + lane;
         bool keep = false;
@@ -219,6 +475,7 @@ __global__ void __launch_bounds__(64) k4_update(K4Args a)
         }
         base += __popcll(m);
     }
+    }
     if (lane == 0) {
         a.n_tracks[s] = base;
         a.n_new[s] = created;
@@ -226,12 +483,12 @@ __global__ void __launch_bounds__(64) k4_update(K4Args a)
         a.processed[s] = process ? 1 : 0;
         if (overflow) atomicOr(a.flags, 1);
         if (!F64SRC && a.gate_cfg) {                 // _adjust_adaptive_state(len(filtered), len(tracks)), pipeline.py:242-262
-            if (g_on) {
-                if (n_emit > 0 || base > 0) { g_idle = 0; g_pe = 1; }
-                else { ++g_idle; if (g_idle >= g_tol) g_pe = g_maxpe > 1 ? g_maxpe : 1; }
+            if (g.on) {
+                if (n_emit > 0 || base > 0) { g.idle = 0; g.pe = 1; }
+                else { ++g.idle; if (g.idle >= g.tol) g.pe = g.maxpe > 1 ? g.maxpe : 1; }
             }
             int32_t *st = a.gate_state + 4 * s;
-            st[0] = g_fi; st[1] = g_idle; st[2] = g_pe;
+            st[0] = g.fi; st[1] = g.idle; st[2] = g.pe;
         }
     }
 }
@@ -276,7 +533,13 @@ __global__ void __launch_bounds__(64) k4_assign_ids(int64_t *id, const int32_t *
     }
 }
 
-size_t k4_smem_bytes(int cap) { return (size_t)cap * (4 * 8 + 8 + 8 + 4 * 4) + 64; }
+// dynamic LDS of k4_update: the staged table of the in-loop form, or match counters + the V ring of the matrix form
+size_t k4_smem_bytes(int cap, bool matrix)
+{
+    const size_t legacy = (size_t)cap * (4 * 8 + 8 + 8 + 4 * 4) + 64;
+    const size_t mx = matrix ? (((size_t)cap * 4 + 1023) & ~(size_t)1023) + K4_RING_BYTES : 0;
+    return legacy > mx ? legacy : mx;
+}
 
 int launch_update(rva_tracker *t, K4Args &a, bool f64, hipStream_t stream)
 {
@@ -284,9 +547,13 @@ int launch_update(rva_tracker *t, K4Args &a, bool f64, hipStream_t stream)
     a.n_tracks = t->n_tracks; a.n_new = t->n_new; a.flags = t->flags;
     a.emitted = t->emitted; a.processed = t->processed;
     a.cap = t->cap; a.max_age = t->max_age; a.min_hits = t->min_hits; a.min_iou = t->min_iou;
-    const size_t smem = k4_smem_bytes(t->cap);
+    const size_t smem = k4_smem_bytes(t->cap, t->d_V != nullptr);
+    a.V = f64 ? nullptr : t->d_V; a.dm = t->dm; a.ld = t->ld;
     if (f64) k4_update<true><<<t->n_streams, 64, smem, stream>>>(a);
-    else k4_update<false><<<t->n_streams, 64, smem, stream>>>(a);
+    else {
+        if (a.V && a.boxes32) k4_iou<<<dim3(K4_IOU_BX, t->n_streams), 256, 0, stream>>>(a);
+        k4_update<false><<<t->n_streams, 64, smem, stream>>>(a);
+    }
     RVA_HIP(t->ctx, hipGetLastError());
     return RVA_OK;
 }
@@ -300,7 +567,17 @@ int rva_tracker_create(rva_ctx *ctx, int n_streams, int capacity, int max_age, d
 {
     if (!ctx || !out || n_streams <= 0 || n_streams > RVA_MAX_TRACKER_STREAMS || capacity <= 0)
         return rva_fail(ctx, RVA_ERR_ARG, "rva_tracker_create: bad argument (1 <= n_streams <= %d)", RVA_MAX_TRACKER_STREAMS);
-    const size_t smem = k4_smem_bytes(capacity);
+    // IoU matrix of a tick (k4_iou -> k4_update): up to dm detections per frame against cap tracks + dm detections, kept
+    // within 512 MiB for all streams; busier frames (and capacities beyond 1024 rows) use the in-loop form
+    int dm = 0, ld = 0;
+    if (capacity <= 64 * K4_RMAX) {
+        const int cap_r = k4_round128_host(capacity);
+        dm = cap_r < 512 ? cap_r : 512;
+        while (dm > 128 && (size_t)n_streams * dm * (cap_r + dm) * 8 > ((size_t)512 << 20)) dm -= 128;
+        if ((size_t)n_streams * dm * (cap_r + dm) * 8 > ((size_t)512 << 20)) dm = 0;
+        ld = cap_r + dm;
+    }
+    const size_t smem = k4_smem_bytes(capacity, dm > 0);
     if (smem > 160 * 1024) return rva_fail(ctx, RVA_ERR_CAPACITY, "tracker capacity %d needs %zu B of LDS (max 160 KiB)", capacity, smem);
     RVA_HIP(ctx, hipSetDevice(ctx->device));
     RVA_HIP(ctx, rva_func_smem((const void *)k4_update<true>, smem));
@@ -329,6 +606,10 @@ int rva_tracker_create(rva_ctx *ctx, int n_streams, int capacity, int max_age, d
     {
         std::vector<double> ones(n_streams, 1.0);
         RVA_HIP(ctx, hipMemcpy(t->d_bscale, ones.data(), n_streams * 8, hipMemcpyHostToDevice));
+    }
+    if (dm > 0) {
+        RVA_HIP(ctx, hipMalloc(&t->d_V, (size_t)n_streams * dm * ld * sizeof(double)));
+        t->dm = dm; t->ld = ld;
     }
     RVA_HIP(ctx, hipMalloc(&t->gate_cfg, n_streams * 16));
     RVA_HIP(ctx, hipMalloc(&t->gate_state, n_streams * 16));
@@ -362,7 +643,7 @@ void rva_tracker_destroy(rva_tracker *t)
     (void)hipSetDevice(t->ctx->device);
     (void)hipDeviceSynchronize();
     void *dev[] = {t->id, t->box, t->conf, t->cls, t->age, t->hits, t->last_det, t->n_tracks, t->n_new, t->next_id, t->id_ticket, t->flags,
-                   t->d_slot, t->d_offs, t->d_gidx, t->d_bscale, t->gate_cfg, t->gate_state, t->emitted, t->processed};
+                   t->d_slot, t->d_offs, t->d_gidx, t->d_bscale, t->gate_cfg, t->gate_state, t->emitted, t->processed, t->d_V};
     for (void *p : dev) (void)hipFree(p);
     void *host[] = {t->h_slot, t->h_offs, t->h_read[0], t->h_read[1]};
     for (int i = 0; i < 2; ++i) if (t->snap_done[i]) (void)hipEventDestroy(t->snap_done[i]);

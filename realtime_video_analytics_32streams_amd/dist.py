@@ -55,11 +55,30 @@ class IdSync:
     def __init__(self, streams_per_rank: int, device: torch.device, group=None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.backend = dist.get_backend(group) if dist.is_initialized() else "none"
         self.per = streams_per_rank
         self.buf = torch.zeros(self.world * streams_per_rank, dtype=torch.int32, device=device)
+        self.calls = 0
+        self.sample_every = 0          # > 0: bracket every n-th exchange with timing events on the calling stream
+        self._events: list = []
+
+    def exchange_us(self) -> List[float]:
+        """Device time of the sampled exchanges (call after a synchronize)."""
+        return [a.elapsed_time(b) * 1e3 for a, b in self._events]
 
     def all_gather_counts(self, local_counts: torch.Tensor) -> torch.Tensor:
         assert local_counts.numel() == self.per and local_counts.dtype == torch.int32
+        self.calls += 1
+        if self.sample_every and self.buf.is_cuda and self.calls % self.sample_every == 0:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            out = self._gather(local_counts)
+            b.record()
+            self._events.append((a, b))
+            return out
+        return self._gather(local_counts)
+
+    def _gather(self, local_counts: torch.Tensor) -> torch.Tensor:
         if self.world == 1:
             self.buf.copy_(local_counts)
         elif dist.get_backend(self.group) == "gloo" and self.buf.is_cuda:   # rehearsal mode: stage through the host

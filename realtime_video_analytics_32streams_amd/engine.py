@@ -476,6 +476,7 @@ class FusedYoloV8:
             assert d1 == d2
             mine["variant"] = theirs["variant"]
         self.tuning = list(getattr(other, "tuning", []))
+        self.tuning_source = "copied from the first slot's plan"
 
     def _refine_in_plan(self, reps: int = 12, within: float = 1.25) -> None:
         import os

@@ -312,6 +312,38 @@ def build_detector_net(scale: str = "s", seed: int = 0, weights: Optional[str] =
 
 
 @torch.no_grad()
+def density_shifts(class_logits: torch.Tensor, conf_thr: float, target_per_image: float, iters: int = 24,
+                   objectness_quantile: float = 0.95) -> Tuple[float, float]:
+    """The two class-bias shifts (class 0, classes >= 1) under which about ``target_per_image`` anchors per image clear
+    ``conf_thr`` with the reference's score rule (score = p[class0] * max_k p[class k>=1]).  Class 0
+    acts as "objectness": the anchors above ``objectness_quantile`` of its logit are made confident (p = 0.9), the other
+    shift is bisected.  Nothing is modified."""
+    z = class_logits.float()
+    z0, zr = z[:, 0], z[:, 1:].max(1).values
+    want = target_per_image * z.shape[0]
+
+    def count(s0, sr):
+        return int(((torch.sigmoid(z0 + s0) * torch.sigmoid(zr + sr)) >= conf_thr).sum())
+
+    q = torch.quantile(z0.flatten()[:2_000_000], objectness_quantile).item()
+    s0 = math.log(0.9 / 0.1) - q
+    lo, hi = -40.0, 40.0
+    for _ in range(iters):
+        mid = 0.5 * (lo + hi)
+        if count(s0, mid) > want:
+            hi = mid
+        else:
+            lo = mid
+    return s0, 0.5 * (lo + hi)
+
+
+def apply_class_shifts(net: "YoloV8", s0: float, sr: float) -> None:
+    for seq in net.detect.cls:
+        seq[-1].bias.data[0] += s0
+        seq[-1].bias.data[1:] += sr
+
+
+@torch.no_grad()
 def calibrate_detection_density(net: YoloV8, sample: Optional[torch.Tensor], conf_thr: float, target_per_image: int = 120,
                                 iters: int = 24, class_logits: Optional[torch.Tensor] = None) -> Tuple[float, float]:
     """Synthetic-weight helper (bench / smoke only): shift the class-branch biases so that about
@@ -323,25 +355,6 @@ def calibrate_detection_density(net: YoloV8, sample: Optional[torch.Tensor], con
         _, cls = net(sample, raw=True)
     else:
         cls = class_logits           # [B, nc, A] class logits obtained elsewhere (e.g. logit of the fused plan's probabilities)
-    z = cls.float()
-    z0, zr = z[:, 0], z[:, 1:].max(1).values
-    want = target_per_image * z.shape[0]
-
-    def count(s0, sr):
-        return int(((torch.sigmoid(z0 + s0) * torch.sigmoid(zr + sr)) >= conf_thr).sum())
-
-    # class 0 acts as "objectness": make the top ~5% of anchors confident, then bisect the rest
-    q = torch.quantile(z0.flatten()[:2_000_000], 0.95).item()
-    s0 = math.log(0.9 / 0.1) - q
-    lo, hi = -40.0, 40.0
-    for _ in range(iters):
-        mid = 0.5 * (lo + hi)
-        if count(s0, mid) > want:
-            hi = mid
-        else:
-            lo = mid
-    sr = 0.5 * (lo + hi)
-    for seq in net.detect.cls:
-        seq[-1].bias.data[0] += s0
-        seq[-1].bias.data[1:] += sr
+    s0, sr = density_shifts(cls, conf_thr, target_per_image, iters)
+    apply_class_shifts(net, s0, sr)
     return s0, sr

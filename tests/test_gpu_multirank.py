@@ -31,6 +31,9 @@ def test_bench_self_spawns_two_ranks_weak():
     j = _run(["--streams", "4"])
     assert j["n_gpus"] == 2 and j["steps"] == 6 and j["scaling"] == "weak" and j["value"] > 0
     assert j["config"]["streams_per_gpu"] == 4 and "sharded 4 per GPU over 2 GPUs" in j["config"]["workload"]
+    m = j["multi_gpu"]                                             # the record shows by itself that two ranks ran
+    assert m["ranks_seen"] == 2 and m["backend"] == "gloo" and m["shared_gpu_rehearsal"] is True
+    assert m["per_rank_frames_per_s"]["min"] > 0 and m["id_exchanges_per_rank"] >= 6 and m["id_exchange_us_per_tick"]["mean"] > 0
 
 
 def test_bench_self_spawns_two_ranks_strong():

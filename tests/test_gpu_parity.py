@@ -93,6 +93,39 @@ def test_postprocess_worst_case_every_anchor_is_a_candidate():
     assert np.array_equal(got["boxes"], want["boxes"]) and np.array_equal(got["conf"], want["conf"])
 
 
+def test_postprocess_busy_images_take_the_suppression_matrix_path():
+    """Images with 129 ... 4096 sorted candidates leave k3_nms after the sort (k3_mask builds the suppression matrix on all
+    CUs, k3_reduce replays the greedy loop over it); 128 and fewer, and more than 4096, finish inside k3_nms.  One batch with
+    candidate counts on both sides of both limits, chunk-boundary counts included; every image against the oracle."""
+    rng = np.random.default_rng(11)
+    A = 8400
+    counts = [128, 129, 191, 192, 193, 1000, 2500, 4095, 4096, 4097, 0, 64]
+    heads = np.zeros((len(counts), 84, A), np.float32)
+    for b, k in enumerate(counts):
+        p = np.zeros((A, 84), np.float32)
+        idx = rng.permutation(A)[:k]                              # the candidates sit anywhere in anchor order
+        # dense scene: boxes cluster around 40 centres, so that most candidates are suppressed by an earlier one
+        c = rng.integers(0, 40, k)
+        cx0, cy0 = rng.uniform(60, 580, 40), rng.uniform(160, 480, 40)
+        p[idx, 0] = cx0[c] + rng.normal(0, 6, k); p[idx, 1] = cy0[c] + rng.normal(0, 6, k)
+        p[idx, 2] = rng.uniform(30, 90, k); p[idx, 3] = rng.uniform(30, 90, k)
+        p[idx, 4] = rng.uniform(0.9, 1.0, k)
+        p[idx, 5:] = rng.uniform(0.3, 1.0, (k, 79)).astype(np.float32)
+        heads[b] = p.T
+    t = torch.from_numpy(heads).to(DEV)
+    for thr in (0.45, 0.9):                                       # few survivors / many survivors per chunk
+        res = ops.postprocess(t, 0.25, thr, None, [N.letterbox(1920, 1080, 640, 640)]).to_host()
+        for b, k in enumerate(counts):
+            want = orc.postprocess(heads[b], 0.25, thr, None, (1920, 1080))
+            got = res[b]
+            assert want["n_cand"] == k == got["n_cand"], (b, k)
+            assert got["n"] == want["n"], (thr, k, got["n"], want["n"])
+            assert np.array_equal(got["anchor"], want["anchor"]) and np.array_equal(got["keep"], want["keep"]), (thr, k)
+            assert np.array_equal(got["cls"], want["cls"]) and np.array_equal(got["conf"], want["conf"])
+            assert np.array_equal(got["boxes"], want["boxes"])
+    assert ops.post_status() == 0
+
+
 def test_postprocess_properties_at_full_size():
     """Size-independent properties on the [32,84,8400] workload: idempotence of NMS on its own
     output, descending scores, every kept pair has IoU <= thr."""
@@ -227,6 +260,64 @@ def test_tracker_fused_f32_path_with_filter_and_skips():
         for s, w in want.items():
             assert _gpu_table(tabs[s]) == orc.table_of(w), (t, s)
     assert trk.state()[0] == ref.next_id
+    trk.close()
+
+
+@pytest.mark.parametrize("cfg", [
+    # S, T, n_obj, capacity, max_det, (max_age, min_iou, min_hits), filter threshold, box scale of stream 1
+    dict(S=32, T=50, n_obj=256, cap=1024, max_det=512, trk=(5, 0.3, 2), thr=0.45, scale=1.0),    # the load sweep's busy scene
+    dict(S=4, T=30, n_obj=300, cap=1024, max_det=512, trk=(30, 0.5, 1), thr=0.3, scale=2.0),     # _rescale_detections inside
+    dict(S=3, T=12, n_obj=580, cap=1024, max_det=1024, trk=(1, 0.5, 1), thr=0.3, scale=1.0),     # frames beyond the matrix's 512 detections
+    dict(S=5, T=40, n_obj=40, cap=160, max_det=128, trk=(3, 0.4, 1), thr=0.5, scale=1.0),        # capacity that is no multiple of the 128-column pad
+], ids=["32x256x50", "rescaled", "beyond-matrix", "small-capacity"])
+def test_tracker_busy_frames_matrix_form_equals_reference_scan(cfg):
+    """K4 under load: k4_iou fills the float64 IoU matrix of the tick on all CUs, k4_update only picks maxima -- the tables
+    after EVERY tick must equal the oracle's sequential scan (ids, hits, ages, float64 boxes), in dense scenes where a
+    detection often has several candidate tracks, matches a track created or moved earlier in the same frame, and where
+    three classes share the frame.  Skipped frames and idle streams ride along."""
+    S, T = cfg["S"], cfg["T"]
+    script = synth.make_tracker_script(97 + cfg["n_obj"], S, T, n_obj=cfg["n_obj"])
+    max_age, min_iou, min_hits = cfg["trk"]
+    trk = ops.DeviceTracker(S, max_age, min_iou, min_hits, capacity=cfg["cap"])
+    ref = orc.Tracker(S, max_age, min_iou, min_hits)
+    scales = [1.0] * S
+    scales[1] = cfg["scale"]
+    if cfg["scale"] != 1.0:
+        trk.set_box_scale(scales)
+    md = cfg["max_det"]
+    post = ops.PostBuffers.allocate(S, md, DEV)
+    rng = np.random.default_rng(1)
+    seen_multi = 0
+    for t in range(T):
+        boxes, scores = np.zeros((S, md, 4), np.float32), np.zeros((S, md), np.float32)
+        cls, counts = np.zeros((S, md), np.int32), np.zeros(S, np.int32)
+        slots, want, row = [], {}, 0
+        for s in range(S):
+            fd = script[t][s]
+            u = rng.random()
+            if u < 0.04:
+                slots.append(-1)
+                continue
+            if u < 0.08:
+                slots.append(-2)
+                want[s] = ref.update(s, np.zeros((0, 4)), [], [])
+                continue
+            d = min(len(fd.conf), md)
+            boxes[row, :d] = fd.boxes[:d]; scores[row, :d] = fd.conf[:d]; cls[row, :d] = fd.cls[:d]; counts[row] = d
+            slots.append(row)
+            m = fd.conf[:d] >= cfg["thr"]
+            want[s] = ref.update(s, fd.boxes[:d][m] * scales[s], fd.conf[:d][m], fd.cls[:d][m])
+            seen_multi = max(seen_multi, d)
+            row += 1
+        post.boxes.copy_(torch.from_numpy(boxes)); post.scores.copy_(torch.from_numpy(scores))
+        post.cls.copy_(torch.from_numpy(cls)); post.counts.copy_(torch.from_numpy(counts))
+        trk.update_from_post(slots, post, cfg["thr"])
+        trk.assign_ids()
+        tabs = trk.read_all()
+        for s, w in want.items():
+            assert _gpu_table(tabs[s]) == orc.table_of(w), (t, s)
+    assert trk.state() == (ref.next_id, 0)
+    assert seen_multi >= min(cfg["n_obj"] * 0.8, md * 0.8)
     trk.close()
 
 
