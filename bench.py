@@ -459,7 +459,11 @@ def end_to_end_load_sweep(args, sources, rctx, dev, dcfg, tcfg, light_fps):
     """Frames/s of the WHOLE pipeline (same runner, same streams) with the synthetic head re-calibrated so that about 64 and
     about 256 boxes per frame survive NMS -- the headline scene keeps ~13.  The class-bias shifts are bisected on the heads of
     8 sample frames pushed through K2/K3 (boxes of the fused plan + shifted class probabilities), then a fresh detector /
-    tracker / runner is timed for 150 ticks after 30 warm-up ticks."""
+    tracker / runner is timed for 150 ticks after 30 warm-up ticks.  The scene of these legs is STATIC (every stream shows
+    one frame over and over): the detections repeat, every track is matched every tick, so tracks per stream ~ boxes kept
+    per frame and K4 sees D detections x D tracks -- the load the sweep is named for.  (With the two alternating frames of
+    the headline run and these random-weight heads, tracks churn and pile up for max_age = 30 ticks: an unbounded table in
+    the reference, an overflow error here.)"""
     import copy
     from realtime_video_analytics_32streams_amd import _native as N
     from realtime_video_analytics_32streams_amd import ops
@@ -468,6 +472,7 @@ def end_to_end_load_sweep(args, sources, rctx, dev, dcfg, tcfg, light_fps):
     from realtime_video_analytics_32streams_amd.engine import FusedYoloV8
     from realtime_video_analytics_32streams_amd.pipeline import PipelinedTicks, TickPipeline
     from realtime_video_analytics_32streams_amd.tracker import IouTracker
+    from realtime_video_analytics_32streams_amd.video_stream import SyntheticNv12Stream
     from realtime_video_analytics_32streams_amd.yolov8 import apply_class_shifts, build_detector_net, density_shifts
     S = len(sources)
     base_net = build_detector_net(args.model, seed=0)
@@ -505,8 +510,12 @@ def end_to_end_load_sweep(args, sources, rctx, dev, dcfg, tcfg, light_fps):
         apply_class_shifts(net, *shifts)
         det = HipYoloDetector(dcfg, net=net, device=dev.index)
         streams = [StreamConfig(name=src.config.name, url=src.config.url, target_fps=30.0, warmup_seconds=0.0) for src in sources]
+        still = [SyntheticNv12Stream(st, index=src.index, width=src.width, height=src.height, n_unique=1, device=dev)
+                 for st, src in zip(streams, sources)]
+        for src in still:
+            src.open_sync()
         trk = IouTracker(tcfg, max_streams=S, capacity=1024, device=dev.index)
-        pipe = TickPipeline(streams, det, trk, sources=sources)
+        pipe = TickPipeline(streams, det, trk, sources=still)
         runner = PipelinedTicks(pipe, depth=args.depth, use_graph=not args.no_graph)
         for _ in range(30):
             runner.submit(); runner.collect()
@@ -528,8 +537,8 @@ def end_to_end_load_sweep(args, sources, rctx, dev, dcfg, tcfg, light_fps):
                                "kept_per_frame": round(float(runner.last_post.counts.float().mean().item()), 1),
                                "candidates_per_frame_calibrated": round(cand, 0), "tracks_per_stream": round(rows / (K * S), 1),
                                "vs_light_load": round(fps / light_fps, 4)}
-        del runner, pipe, trk, det
-    return {"streams": S, "ticks": 150, "light_load_frames_per_s": light_fps, **legs}
+        del runner, pipe, trk, det, still
+    return {"streams": S, "ticks": 150, "scene": "static (one frame per stream, repeated)", "light_load_frames_per_s": light_fps, **legs}
 
 
 def decode_stage(dev):

@@ -412,8 +412,10 @@ int rva_decoder_feed(rva_decoder *dec, const uint8_t *data, int size, int64_t pt
 
 /* Next picture in display order: *pic_index >= 0 and device pointers *y / *uv (interleaved) with a common *pitch, the
  * display size *width x *height (cropped to whole chroma pairs), or *pic_index == -1 when nothing is displayable yet
- * (feed more data).  Waits for that picture's decode to finish.  The surface stays valid until
- * rva_decoder_release(dec, pic_index) hands it back to the decoder's pool. */
+ * (feed more data).  Waits for that picture's decode to finish.  *pic_index is a ticket (decoder generation << 10 | the
+ * library's picture index): the surface stays valid until rva_decoder_release(dec, that ticket) hands it back -- also
+ * across a change of picture size mid-stream, where the previous decoder lives on until its last picture is released.
+ * The library probed first is the one RVA_ROCDECODE_LIB names (then librocdecode.so on the default search path). */
 int rva_decoder_next_frame(rva_decoder *dec, void **y, void **uv, int32_t *pitch, int32_t *width, int32_t *height,
                            int64_t *pts, int32_t *pic_index);
 int rva_decoder_release(rva_decoder *dec, int pic_index);

@@ -8,8 +8,9 @@
 // dependency on it: on a machine without the library rva_decoder_create() returns RVA_ERR_UNAVAILABLE and everything
 // else keeps working (rva_decode_available() is the probe).  Compiled against the rocDecode 0.10 headers that ship in
 // the ROCm image (rocprofiler-sdk/rocdecode/details).  NOTE: neither the build container nor the GPU boxes of this
-// project carry librocdecode.so, so this translation unit has been compiled but never executed there; the host-side
-// demuxer (mp4.py) and the capture loop around it are the parts covered by tests.
+// project carry librocdecode.so.  What executes this translation unit there is a TEST DOUBLE (tests/mock_rocdecode/, named
+// through RVA_ROCDECODE_LIB): it drives the callbacks, the display queue, the display-area crop, the hold / release of
+// mapped pictures, the end-of-stream flush and a mid-stream change of picture size, and pins nothing about VCN pixels.
 #include <dlfcn.h>
 
 #include <deque>
@@ -48,8 +49,11 @@ RocDecApi *rocdec_api(std::string *why)
     std::lock_guard<std::mutex> g(mu);
     if (!tried) {
         tried = true;
-        const char *names[] = {"librocdecode.so", "librocdecode.so.1", "librocdecode.so.0", "/opt/rocm/lib/librocdecode.so"};
+        // RVA_ROCDECODE_LIB: an explicit library path tried first (a rocDecode build outside the default search path)
+        const char *names[] = {getenv("RVA_ROCDECODE_LIB"), "librocdecode.so", "librocdecode.so.1", "librocdecode.so.0",
+                               "/opt/rocm/lib/librocdecode.so"};
         for (const char *nm : names) {
+            if (!nm || !*nm) continue;
             api.lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
             if (api.lib) { api.where = nm; break; }
         }
@@ -86,14 +90,20 @@ struct rva_decoder {
     RocDecApi *api = nullptr;
     rocDecVideoCodec codec = rocDecVideoCodec_HEVC;
     RocdecVideoParser parser = nullptr;
-    rocDecDecoderHandle dec = nullptr;
+    rocDecDecoderHandle dec = nullptr;   // decoder of the current sequence (= gens.back().dec)
     int want_surfaces = 0;
     // sequence state (sequence callback)
     uint32_t coded_w = 0, coded_h = 0;
     int disp_w = 0, disp_h = 0, crop_left = 0, crop_top = 0;
     uint32_t surfaces = 0;
+    // A decoder lives as long as pictures of it are queued for display or mapped by the caller: a change of picture size
+    // mid-stream starts a new generation, the old decoder is destroyed when its last picture has been released (the
+    // parser flushes the old sequence's pictures through the display callback right before it announces the new one).
+    struct Gen { int id; rocDecDecoderHandle dec; int disp_w, disp_h, crop_left, crop_top; int outstanding; };
+    std::deque<Gen> gens;
+    int next_gen = 0;
     // display queue (display callback -> rva_decoder_next_frame)
-    struct Ready { int pic; int64_t pts; };
+    struct Ready { int pic; int64_t pts; int gen; };
     std::deque<Ready> ready;
     bool eos_sent = false;
     std::string cb_error;           // first error raised inside a callback (callbacks cannot return text)
@@ -118,10 +128,12 @@ int ROCDECAPI on_sequence(void *user, RocdecVideoFormat *fmt)
     const uint32_t n = fmt->min_num_decode_surfaces > (uint32_t)d->want_surfaces ? fmt->min_num_decode_surfaces : (uint32_t)d->want_surfaces;
     const int dw = fmt->display_area.right - fmt->display_area.left, dh = fmt->display_area.bottom - fmt->display_area.top;
     if (d->dec && fmt->coded_width == d->coded_w && fmt->coded_height == d->coded_h && n <= d->surfaces) return (int)d->surfaces;
-    if (d->dec) {   // resolution change mid-stream: start over with a decoder of the new size
-        d->api->DestroyDecoder(d->dec);
+    if (d->dec) {   // resolution change mid-stream: a decoder of the new size; the old one goes when its pictures are back
         d->dec = nullptr;
-        d->ready.clear();
+        if (!d->gens.empty() && d->gens.back().outstanding == 0) {
+            d->api->DestroyDecoder(d->gens.back().dec);
+            d->gens.pop_back();
+        }
     }
     if (d->api->GetDecoderCaps) {
         RocdecDecodeCaps caps{};
@@ -163,6 +175,7 @@ int ROCDECAPI on_sequence(void *user, RocdecVideoFormat *fmt)
     d->coded_w = fmt->coded_width; d->coded_h = fmt->coded_height;
     d->disp_w = dw; d->disp_h = dh; d->crop_left = fmt->display_area.left; d->crop_top = fmt->display_area.top;
     d->surfaces = n;
+    d->gens.push_back({d->next_gen++, d->dec, d->disp_w, d->disp_h, d->crop_left, d->crop_top, 0});
     return (int)n;       // > 1: the parser adopts this as its DPB size
 }
 
@@ -179,7 +192,12 @@ int ROCDECAPI on_display(void *user, RocdecParserDispInfo *info)
 {
     rva_decoder *d = static_cast<rva_decoder *>(user);
     if (!info) return 1;     // end-of-stream marker (ROCDEC_PKT_NOTIFY_EOS)
-    d->ready.push_back({info->picture_index, (int64_t)info->pts});
+    if (d->gens.empty() || info->picture_index < 0 || info->picture_index >= 1024) {
+        if (d->cb_error.empty()) d->cb_error = "display callback without a decoder / with a picture index out of range";
+        return 0;
+    }
+    d->gens.back().outstanding += 1;
+    d->ready.push_back({info->picture_index, (int64_t)info->pts, d->gens.back().id});
     return 1;
 }
 
@@ -232,7 +250,7 @@ void rva_decoder_destroy(rva_decoder *d)
 {
     if (!d) return;
     if (d->parser) d->api->DestroyVideoParser(d->parser);
-    if (d->dec) d->api->DestroyDecoder(d->dec);
+    for (auto &g : d->gens) d->api->DestroyDecoder(g.dec);
     delete d;
 }
 
@@ -258,26 +276,29 @@ int rva_decoder_next_frame(rva_decoder *d, void **y, void **uv, int32_t *pitch, 
 {
     if (!d || !y || !uv || !pitch || !width || !height || !pic_index) return RVA_ERR_ARG;
     *pic_index = -1;
-    if (d->ready.empty() || !d->dec) return RVA_OK;             // nothing displayable yet: feed more data
+    if (d->ready.empty()) return RVA_OK;                        // nothing displayable yet: feed more data
     const rva_decoder::Ready r = d->ready.front();
     d->ready.pop_front();
+    rva_decoder::Gen *g = nullptr;
+    for (auto &x : d->gens) if (x.id == r.gen) g = &x;
+    if (!g) return rva_fail(d->ctx, RVA_ERR_HIP, "decode: a queued picture outlived its decoder");
     void *planes[3] = {nullptr, nullptr, nullptr};
     uint32_t pitches[3] = {0, 0, 0};
     RocdecProcParams proc{};
     proc.progressive_frame = 1;
-    rocDecStatus st = d->api->GetVideoFrame(d->dec, r.pic, planes, pitches, &proc);   // waits for the picture, maps it for HIP
+    rocDecStatus st = d->api->GetVideoFrame(g->dec, r.pic, planes, pitches, &proc);   // waits for the picture, maps it for HIP
     if (st != ROCDEC_SUCCESS) return rva_fail(d->ctx, RVA_ERR_HIP, "rocDecGetVideoFrame failed: %s", dec_err(d, st));
     if (!planes[0] || !planes[1] || pitches[0] == 0 || pitches[1] != pitches[0])
         return rva_fail(d->ctx, RVA_ERR_HIP, "rocDecGetVideoFrame returned an unexpected NV12 layout (pitch %u / %u)", pitches[0], pitches[1]);
     // crop to the display area: whole chroma sample pairs only (K1 addresses UV at (y >> 1, (x >> 1) << 1))
-    const int cx = d->crop_left & ~1, cy = d->crop_top & ~1;
+    const int cx = g->crop_left & ~1, cy = g->crop_top & ~1;
     *y = (uint8_t *)planes[0] + (size_t)cy * pitches[0] + cx;
     *uv = (uint8_t *)planes[1] + (size_t)(cy >> 1) * pitches[1] + cx;
     *pitch = (int32_t)pitches[0];
-    *width = d->disp_w & ~1;
-    *height = d->disp_h & ~1;
+    *width = g->disp_w & ~1;
+    *height = g->disp_h & ~1;
     if (pts) *pts = r.pts;
-    *pic_index = r.pic;
+    *pic_index = (r.gen << 10) | r.pic;       // the ticket rva_decoder_release takes back: decoder generation + picture
     ++d->frames_out;
     return RVA_OK;
 }
@@ -285,11 +306,25 @@ int rva_decoder_next_frame(rva_decoder *d, void **y, void **uv, int32_t *pitch, 
 int rva_decoder_release(rva_decoder *d, int pic_index)
 {
     if (!d || pic_index < 0) return RVA_ERR_ARG;
-    if (d->api->ParserMarkFrameForReuse && d->parser) {
-        rocDecStatus st = d->api->ParserMarkFrameForReuse(d->parser, pic_index);
-        if (st != ROCDEC_SUCCESS) return rva_fail(d->ctx, RVA_ERR_HIP, "rocDecParserMarkFrameForReuse failed: %s", dec_err(d, st));
+    const int gen = pic_index >> 10, pic = pic_index & 1023;
+    for (size_t i = 0; i < d->gens.size(); ++i) {
+        rva_decoder::Gen &g = d->gens[i];
+        if (g.id != gen) continue;
+        if (g.outstanding <= 0) return rva_fail(d->ctx, RVA_ERR_ARG, "rva_decoder_release: picture %d was not handed out", pic_index);
+        g.outstanding -= 1;
+        const bool current = g.dec == d->dec;
+        if (!current && g.outstanding == 0) {                   // last picture of a retired decoder
+            d->api->DestroyDecoder(g.dec);
+            d->gens.erase(d->gens.begin() + (long)i);
+            return RVA_OK;
+        }
+        if (current && d->api->ParserMarkFrameForReuse && d->parser) {   // the parser's pool belongs to the current sequence
+            rocDecStatus st = d->api->ParserMarkFrameForReuse(d->parser, pic);
+            if (st != ROCDEC_SUCCESS) return rva_fail(d->ctx, RVA_ERR_HIP, "rocDecParserMarkFrameForReuse failed: %s", dec_err(d, st));
+        }
+        return RVA_OK;
     }
-    return RVA_OK;
+    return rva_fail(d->ctx, RVA_ERR_ARG, "rva_decoder_release: picture %d belongs to no live decoder", pic_index);
 }
 
 }  // extern "C"
