@@ -502,21 +502,30 @@ int preprocess_common(rva_ctx *ctx, bool nv12, int mode, const void *const *p0, 
     if (mode != 2 && !out_aligned && (dst_w % 8 == 0))  // vector stores need 16-byte rows
         return rva_fail(ctx, RVA_ERR_ARG, "output tensor must be 16-byte aligned");
     dim3 grid(rva_ceil_div(rva_ceil_div(dst_w, 8) * dst_h, 256), n);
+    // one-shot profiling events (rva_profile_next_preprocess) bracket the generic kernel too
+    hipEvent_t ge0 = ctx->k1_start, ge1 = ctx->k1_stop;
+    ctx->k1_start = ctx->k1_stop = nullptr;
+#define RVA_LAUNCH_GENERIC_T(NV, MD, T)                                                                           \
+    do {                                                                                                          \
+        if (ge0 && ge1) hipExtLaunchKernelGGL((k1_generic<NV, MD, T>), grid, dim3(256), 0, stream, ge0, ge1, 0, a); \
+        else k1_generic<NV, MD, T><<<grid, 256, 0, stream>>>(a);                                                  \
+    } while (0)
 #define RVA_LAUNCH_GENERIC(NV, MD)                                                         \
     do {                                                                                   \
-        if (out_dtype == RVA_F16) k1_generic<NV, MD, __half><<<grid, 256, 0, stream>>>(a); \
-        else k1_generic<NV, MD, float><<<grid, 256, 0, stream>>>(a);                       \
+        if (out_dtype == RVA_F16) RVA_LAUNCH_GENERIC_T(NV, MD, __half);                    \
+        else RVA_LAUNCH_GENERIC_T(NV, MD, float);                                          \
     } while (0)
     if (mode == 2) { if (nv12) RVA_LAUNCH_GENERIC(true, 2); else RVA_LAUNCH_GENERIC(false, 2); }
     else if (clip && out_dtype == RVA_F64) {
-        if (nv12) k1_generic<true, 1, double><<<grid, 256, 0, stream>>>(a);
-        else k1_generic<false, 1, double><<<grid, 256, 0, stream>>>(a);
+        if (nv12) RVA_LAUNCH_GENERIC_T(true, 1, double);
+        else RVA_LAUNCH_GENERIC_T(false, 1, double);
     }
     else if (nv12 && clip) RVA_LAUNCH_GENERIC(true, 1);
     else if (nv12) RVA_LAUNCH_GENERIC(true, 0);
     else if (clip) RVA_LAUNCH_GENERIC(false, 1);
     else RVA_LAUNCH_GENERIC(false, 0);
 #undef RVA_LAUNCH_GENERIC
+#undef RVA_LAUNCH_GENERIC_T
     RVA_HIP(ctx, hipGetLastError());
     return RVA_OK;
 }

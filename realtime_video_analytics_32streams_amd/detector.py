@@ -199,6 +199,16 @@ class HipYoloDetector(BaseDetector):
         return ops.postprocess(raw, self.config.confidence_threshold, self.config.iou_threshold, self.config.classes,
                                metas, max_det=A, out=self._post, ctx=self.ctx)
 
+    # -- the three stages of a tick, as the pipelined runner drives them (same protocol as the temporal heads) -------------
+    def stage_pre(self, packets: Sequence[FramePacket]):
+        return self._preprocess([p.frame for p in packets])            # (input tensor, letterbox meta)
+
+    def stage_net(self, pre):
+        return self._infer(pre[0])
+
+    def stage_post(self, raw, pre) -> ops.PostBuffers:
+        return self._postprocess_device(raw, [pre[1]])
+
     # -- API ------------------------------------------------------------------------------------
     @staticmethod
     def geometry_key(frame) -> tuple:

@@ -297,6 +297,7 @@ class TickPipeline:
         for g in plan.groups:
             det = self.detectors[g.det]
             post = det.predict_batch_device([packets[i] for i in g.idx])
+            self._note_clips(g, getattr(det, "last_clip_infos", None))
             dev.update_from_post(self._kslot(plan, g, first), post, det.config.confidence_threshold, gated=gated, motion=motion)
             posts.append(post)
             first = False
@@ -305,6 +306,15 @@ class TickPipeline:
         self._host_path(plan, packets)
         self.assign_ids()
         return plan, posts
+
+    def _note_clips(self, g: _Group, infos) -> None:
+        """Temporal heads on the device path: remember which clip each stream fired (``finish`` copies the temporal
+        fields into the tracks the clip's detections touched, tracker.py:58-67)."""
+        if infos:
+            self._host_dets = getattr(self, "_host_dets", {})
+            for i in g.idx:
+                if self.names[i] in infos:
+                    self._host_dets[i] = infos[self.names[i]]
 
     def assign_ids(self) -> None:
         dev = self.tracker.device_tracker
@@ -384,15 +394,19 @@ class PipelinedTicks:
 
     def __init__(self, pipe: TickPipeline, depth: int = 2, use_graph: bool = True, overlap: bool = True,
                  net_graph: bool = False, net_streams: int = 2):
-        if any(not hasattr(d, "predict_batch_device") for d in pipe.detectors):
-            raise NotImplementedError("PipelinedTicks needs detectors with a batched device path (temporal heads return host "
-                                      "detections: use TickPipeline.tick)")
+        if any(not hasattr(d, "stage_pre") for d in pipe.detectors):
+            raise NotImplementedError("PipelinedTicks needs detectors with a batched device path (stage_pre / stage_net / "
+                                      "stage_post); a host-only detector runs through TickPipeline.tick")
         if depth not in (1, 2):
             raise ValueError("depth must be 1 or 2 (two snapshot slots, two head tensors)")
         self.pipe, self.depth = pipe, depth
         self.det, self.dt = pipe.detector, pipe.tracker.device_tracker
         self.world_sharded = pipe.id_sync is not None
-        fused = all(d.engine == "fused" and d.half and d._infer_fn is None for d in pipe.detectors)
+        is_fused = lambda d: getattr(d, "engine", None) == "fused" and d.half and d._infer_fn is None      # noqa: E731
+        fused = all(is_fused(d) for d in pipe.detectors)
+        # temporal heads run their (torch) network eagerly; they may still run as two chains: every result buffer of theirs
+        # exists per tick parity and their frame ring has two slots more than a clip needs
+        chains_ok = all(is_fused(d) or getattr(d, "two_chain_ok", False) for d in pipe.detectors)
         self.use_graph = bool(use_graph) and fused
         self._fused = fused
         # The network itself is launched eagerly by default: its plan forks the detect branches onto side streams, which
@@ -401,7 +415,7 @@ class PipelinedTicks:
         # tail on stream B (K2/K3 -> K4 -> ids -> snapshot) is what the captured graph is for.
         self.net_graph = bool(net_graph) and self.use_graph
         # ``overlap=False`` keeps everything on one stream (eager only): the per-stage timing pass of bench.py
-        self.two_streams = (overlap or self.use_graph) and fused              # needs per-parity head tensors
+        self.two_streams = (overlap or self.use_graph) and chains_ok         # needs per-parity result buffers
         self.sA = torch.cuda.current_stream()
         self.sB = torch.cuda.Stream(device=self.det.device) if self.two_streams else self.sA
         # The networks of consecutive ticks run on TWO streams (even ticks on A, odd ticks on A'), each with its own input
@@ -447,15 +461,16 @@ class PipelinedTicks:
         for d in self.pipe.detectors:
             d._slot = par if self.net_streams == 2 else 0
 
-    def _post_part(self, plan, raws, metas, motion, events=None):
-        """Stream-B work of one tick for every group: K2/K3 then K4 (+ filter, rescale, gates)."""
+    def _post_part(self, plan, raws, pres, motion, events=None):
+        """The tail of one tick for every group: K2/K3 (temporal heads: top-5) then K4 (+ filter, rescale, gates).
+        ``pres[g]``: what the group's ``stage_pre`` returned (YOLO: input tensor + letterbox meta)."""
         p = self.pipe
         gated = p.has_gates
         first = True
         for gi, g in enumerate(plan.groups):
             det = p.detectors[g.det]
             with torch.inference_mode():
-                post = det._postprocess_device(raws[gi], [metas[gi]])
+                post = det.stage_post(raws[gi], pres[gi])
             if events and first: events[3].record()
             self.dt.update_from_post(p._kslot(plan, g, first), post, det.config.confidence_threshold, gated=gated, motion=motion)
             self.last_post = post
@@ -468,7 +483,7 @@ class PipelinedTicks:
         if events: events[4].record()
         self.dt.snapshot_async(k & 1)
 
-    def _capture(self, plan, tensors, metas, motion):
+    def _capture(self, plan, pres, motion):
         """Record the networks (per group and head-tensor parity) and the stream-B part (per parity) of a tick of this
         shape.  Nothing executes here; every kernel of the shape has already run eagerly once."""
         p = self.pipe
@@ -480,14 +495,14 @@ class PipelinedTicks:
             pair = []
             for par in (0, 1):
                 self._set_slot(par)
-                fp = self._plan_of(det, tensors[gi])
+                fp = self._plan_of(det, pres[gi][0])
                 # head tensor (group, parity): a stable buffer of the plan (two network streams: of the parity's own plan)
                 raws[gi][par] = fp.use_output(gi if self.net_streams == 2 else 2 * gi + par)
                 if self.net_graph:
                     gr = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(gr):
                         with torch.inference_mode():
-                            det._infer(tensors[gi])                # network only, writes that head tensor
+                            det.stage_net(pres[gi])                # network only, writes that head tensor
                     pair.append(gr)
             self._net_graphs.append(pair)
         torch.cuda.synchronize()
@@ -495,7 +510,7 @@ class PipelinedTicks:
             mo = None if motion is None else (p._motion_gate().counts[par], motion[1])   # the parity's K5 count row
             gr = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gr):
-                self._post_part(plan, [r[par] for r in raws], metas, mo)
+                self._post_part(plan, [r[par] for r in raws], pres, mo)
                 if not self.world_sharded:
                     self._ids_and_snapshot(par)                    # single GPU: ids + snapshot ride in the graph
             self._post_graphs[par] = gr
@@ -513,13 +528,13 @@ class PipelinedTicks:
                 sb.wait_event(self._done[par ^ 1])                 # tails on two streams: tracker state is touched in tick order
             if after is not None:
                 sb.wait_event(after)
-            mode, plan, raws, metas, motion, events = self._pending[par]
+            mode, plan, raws, pres, motion, events = self._pending[par]
             if mode == "graph":
                 self._post_graphs[par].replay()
                 if self.world_sharded:
                     self._ids_and_snapshot(k)                      # the id exchange (RCCL) stays outside the graph
             else:
-                self._post_part(plan, raws, metas, motion, events)
+                self._post_part(plan, raws, pres, motion, events)
                 self._ids_and_snapshot(k, events)
             self._done[par].record(sb)
         self._posted = k
@@ -557,34 +572,39 @@ class PipelinedTicks:
         sig = plan.signature
         replay = self.use_graph and self.two_streams and self._cap_sig == sig
         capture_after = self.use_graph and self.two_streams and not replay and sig in self._seen_sigs
-        tensors, metas, raws = [], [], []
+        pres, raws = [], []
         for gi, g in enumerate(plan.groups):
             det = p.detectors[g.det]
+            plan_det = hasattr(det, "plan_for") and getattr(det, "engine", None) == "fused" and det._infer_fn is None
             with torch.cuda.stream(sk), torch.inference_mode():
                 if events and gi == 0: events[0].record()
                 if before_k1 and gi == 0: before_k1()
-                tensor, meta = det._preprocess([packets[i].frame for i in g.idx])      # K1
+                pre = det.stage_pre([packets[i] for i in g.idx])    # K1 (temporal heads: into the frame ring + clip schedule)
+                p._note_clips(g, getattr(pre, "infos", None))
                 if events and gi == 0: events[1].record()
-                if self.two_streams and gi == 0:
+                if self.two_streams and gi == len(plan.groups) - 1:
                     self._k1_done[par].record(sk)
             with torch.cuda.stream(sa):
                 if self.two_streams and gi == 0 and k >= 2:
                     sa.wait_event(self._done[par])                 # tick k-2 has finished reading the head tensors `par`
-                tensors.append(tensor); metas.append(meta)
+                pres.append(pre)
                 if replay and self.net_graph:
                     self._net_graphs[gi][par].replay()
                 else:
                     with torch.inference_mode():
-                        if self.two_streams:
-                            self._plan_of(det, tensor).use_output(gi if self.net_streams == 2 else 2 * gi + par)
-                        elif self._fused:
-                            self._plan_of(det, tensor)             # sets the plan's branch mode for this runner's layout
-                        raws.append(det._infer(tensor))
+                        if plan_det and self.two_streams:
+                            self._plan_of(det, pre[0]).use_output(gi if self.net_streams == 2 else 2 * gi + par)
+                        elif plan_det:
+                            self._plan_of(det, pre[0])             # sets the plan's branch mode for this runner's layout
+                        raws.append(det.stage_net(pre))
         with torch.cuda.stream(sa):
             if events: events[2].record()
-            self._pending[par] = ("graph" if replay else "eager", plan, None if replay else raws, metas, motion,
+            self._pending[par] = ("graph" if replay else "eager", plan, None if replay else raws, pres, motion,
                                   None if replay else events)
-            self._meta[par] = (packets, t0)
+            clips = dict(getattr(p, "_host_dets", {}))             # clips the temporal heads fired in THIS tick
+            if clips:
+                p._host_dets.clear()
+            self._meta[par] = (packets, t0, clips)
             if self.two_streams:
                 if not plan.groups:
                     self._k1_done[par].record(sk)
@@ -602,13 +622,13 @@ class PipelinedTicks:
             elif k >= 1 and self._posted < k - 1:
                 self._issue_post(k - 1, self._k1_done[par])        # K1 of this tick first, then the previous tail
         else:
-            _, pl, rw, mt, mo, ev = self._pending[par]
-            self._post_part(pl, rw, mt, mo, ev)
+            _, pl, rw, prs, mo, ev = self._pending[par]
+            self._post_part(pl, rw, prs, mo, ev)
             self._ids_and_snapshot(k, ev)
         if capture_after:     # second tick of this shape: everything is sized and warm -> record it for the ticks to come
             if self._posted < k:
                 self._issue_post(k, None)
-            self._capture(plan, tensors, metas, motion)
+            self._capture(plan, pres, motion)
         self._seen_sigs.add(sig)
         self._next += 1
         return k
@@ -635,5 +655,7 @@ class PipelinedTicks:
 
     def collect_result(self) -> TickResult:
         k, tables, status = self._collect()
-        packets, t0 = self._meta[k & 1]
+        packets, t0, clips = self._meta[k & 1]
+        if clips:
+            self.pipe._host_dets = dict(clips)
         return self.pipe.finish(packets, tables, status, t0)

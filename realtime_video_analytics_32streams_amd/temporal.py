@@ -67,6 +67,29 @@ class ClipSchedule:
         return clip, dropped
 
 
+@dataclass
+class ClipInfo:
+    """Host-side facts of the clip a stream fired in a tick (device path): what ``Track`` copies from a
+    ``TemporalDetection`` (tracker.py:58-67) that is not in the track table itself."""
+    start_frame: int
+    end_frame: int
+    labels: Optional[Sequence[str]]
+    n_dets: int
+
+    def label(self, class_id: int) -> Optional[str]:
+        return self.labels[class_id] if self.labels and class_id < len(self.labels) else None
+
+
+@dataclass
+class _ClipTick:
+    """What ``stage_pre`` hands to ``stage_net`` / ``stage_post`` for one tick of one frame group."""
+    rows: int                                   # streams of the group (batch rows of the PostBuffers)
+    fired: List[Tuple[int, List[int], Tuple[int, int]]]   # (row, ring slots of the clip, (h, w) of its first frame)
+    cols: List[int]                             # ring column of every row
+    infos: Dict[str, ClipInfo]
+    slot: int                                   # pipeline slot (tick parity) whose buffers this tick uses
+
+
 class CnnLstmNet(nn.Module):
     """Per-frame conv stem -> 2-layer LSTM -> linear on the last step (the architecture exported by
     scripts/convert_temporal_model_to_onnx.py:34-88, re-expressed with all T frames in one conv batch)."""
@@ -142,6 +165,14 @@ class _HipTemporalDetector:
         self._buf: Dict[str, Deque] = {}
         self._ring: Dict[str, torch.Tensor] = {}
         self._free: Dict[str, List[int]] = {}
+        # batched device path (stage_pre / stage_net / stage_post): one ring for all streams, [slots, columns, 3, H, W]
+        self._slot = 0                         # set by PipelinedTicks: tick parity -> which result buffers a tick uses
+        self._col: Dict[str, int] = {}         # stream name -> ring column
+        self._arrivals: Dict[str, int] = {}    # frames seen per stream (ring slot = arrivals % ring slots)
+        self._bbuf: Dict[str, Deque] = {}      # per stream: (frame_id, ring slot, (h, w)) of the buffered frames
+        self._bring: Optional[torch.Tensor] = None
+        self._post: Dict[tuple, ops.PostBuffers] = {}
+        self.two_chain_ok = True               # PipelinedTicks may run consecutive ticks as two chains on two streams
 
     # -- per-head hooks ---------------------------------------------------------------------------
     def _default_net(self) -> nn.Module:
@@ -189,6 +220,96 @@ class _HipTemporalDetector:
         if clip is None:
             return []
         return self._predict_sequence(name, ring, clip)
+
+    # -- batched device path: a whole tick of this head without a host round trip ----------------------------------------
+    RING_EXTRA = 2        # ring slots beyond the clip buffer: two ticks may be in flight (K1 of tick k+1 beside the network of k)
+
+    @staticmethod
+    def geometry_key(frame) -> tuple:
+        if isinstance(frame, ops.Nv12Surface):
+            return (int(frame.width), int(frame.height), "nv12")
+        return (int(frame.shape[1]), int(frame.shape[0]), "bgr")
+
+    def _columns(self, names: Sequence[str]) -> List[int]:
+        new = [n for n in names if n not in self._col]
+        if new:
+            for n in new:
+                self._col[n] = len(self._col)
+                self._arrivals[n] = 0
+                self._bbuf[n] = deque()
+            slots = self.sched.need + self.RING_EXTRA
+            ring = torch.empty((slots, len(self._col), 3, *self.input_hw), dtype=self._frame_dtype(), device=self.device)
+            if self._bring is not None:
+                ring[:, :self._bring.shape[1]] = self._bring
+            self._bring = ring
+        return [self._col[n] for n in names]
+
+    def stage_pre(self, packets: Sequence[FramePacket]) -> _ClipTick:
+        """K1 of the tick: every frame is pre-processed on arrival straight into its ring slot -- ONE launch when the
+        streams of the group sit in adjacent columns and have seen the same number of frames (the steady state), one
+        launch per stream otherwise -- and the clip schedule (host logic, temporal_detector.py:88-118) advances."""
+        names = [p.stream.name for p in packets]
+        cols = self._columns(names)
+        R = self._bring.shape[0]
+        slots = [self._arrivals[n] % R for n in names]
+        frames = [self._to_device(p.frame) for p in packets]
+        same_geo = len({self.geometry_key(f) for f in frames}) == 1
+        if same_geo and len(set(slots)) == 1 and cols == list(range(cols[0], cols[0] + len(cols))):
+            ops.preprocess_frames(frames, self.input_hw, self.NORM, N.LAYOUT_NCHW, self._frame_dtype(),
+                                  out=self._bring[slots[0], cols[0]:cols[0] + len(cols)], ctx=self.ctx)
+        else:
+            for f, sl, c in zip(frames, slots, cols):
+                ops.preprocess_frames([f], self.input_hw, self.NORM, N.LAYOUT_NCHW, self._frame_dtype(),
+                                      out=self._bring[sl, c:c + 1], ctx=self.ctx)
+        fired, infos = [], {}
+        for row, (p, n, sl) in enumerate(zip(packets, names, slots)):
+            f = p.frame
+            hw = (f.height, f.width) if isinstance(f, ops.Nv12Surface) else (int(f.shape[0]), int(f.shape[1]))
+            self._arrivals[n] += 1
+            clip, _ = self.sched.push(self._bbuf[n], (p.frame_id, sl, hw))
+            if clip is not None:
+                fired.append((row, [c[1] for c in clip], clip[0][2]))
+                infos[n] = ClipInfo(clip[0][0], clip[-1][0], self.config.action_classes, min(5, self.config.num_action_classes))
+        return _ClipTick(len(packets), fired, cols, infos, self._slot)
+
+    def stage_net(self, pre: _ClipTick) -> Optional[torch.Tensor]:
+        """The clips that fired this tick as ONE network batch: ``[n_fired, classes]`` raw outputs (no softmax)."""
+        if not pre.fired:
+            return None
+        C_ = self._bring.shape[1]
+        flat = self._bring.view(-1, 3, *self.input_hw)
+        idx = torch.tensor([[sl * C_ + pre.cols[row] for sl in slots] for row, slots, _ in pre.fired], device=self.device)
+        x = flat.index_select(0, idx.flatten()).view(len(pre.fired), idx.shape[1], 3, *self.input_hw)      # [B,T,3,H,W]
+        if self.CLIP_LAYOUT == "CTHW":
+            x = x.permute(0, 2, 1, 3, 4).contiguous()
+        with torch.inference_mode():
+            return (self._infer_fn(x) if self._infer_fn is not None else self.net(x)).float()
+
+    def stage_post(self, raw: Optional[torch.Tensor], pre: _ClipTick) -> ops.PostBuffers:
+        """Top-5 of the raw output per clip in the reference's order (ascending stable sort, last five reversed:
+        temporal_detector.py:396-398), full-frame boxes (:418); the ``>= confidence_threshold`` test of :402 is the
+        tracker kernel's filter (same float64 comparison).  Streams without a clip this tick get an empty row: their
+        tracks age like ``tracker.update(name, [])``."""
+        key = (pre.rows, pre.slot)
+        post = self._post.get(key)
+        if post is None:
+            post = self._post[key] = ops.PostBuffers.allocate(pre.rows, 8, self.device)
+        post.counts.zero_()
+        if raw is not None:
+            k = min(5, raw.shape[1])
+            order = torch.sort(raw, dim=1, stable=True).indices[:, -k:].flip(1)            # [n_fired, k]
+            rows = torch.tensor([row for row, _, _ in pre.fired], device=self.device)
+            post.scores[rows, :k] = torch.gather(raw, 1, order)
+            post.cls[rows, :k] = order.to(torch.int32)
+            wh = torch.tensor([[0.0, 0.0, float(hw[1]), float(hw[0])] for _, _, hw in pre.fired], device=self.device)
+            post.boxes[rows, :k] = wh[:, None, :]
+            post.counts[rows] = k
+        return post
+
+    def predict_batch_device(self, packets: Sequence[FramePacket]) -> ops.PostBuffers:
+        pre = self.stage_pre(packets)
+        self.last_clip_infos = pre.infos
+        return self.stage_post(self.stage_net(pre), pre)
 
     def _predict_sequence(self, name: str, ring: torch.Tensor, clip) -> List[Detection]:
         idx = torch.tensor([c[1] for c in clip], device=self.device)

@@ -73,6 +73,7 @@ class IouTracker:
     def _materialise(self, stream_name: str, tab: dict, dets: Sequence[Detection]) -> List[Track]:
         live = self._tracks[stream_name]
         fresh: Dict[int, Track] = {}
+        clip = dets if hasattr(dets, "start_frame") else None      # temporal.ClipInfo instead of a detection list
         for i in range(tab["n"]):
             tid = int(tab["id"][i])
             t = live.get(tid)
@@ -84,7 +85,12 @@ class IouTracker:
                 t.confidence = float(tab["conf"][i]); t.bbox_xyxy = box
                 t.age = int(tab["age"][i]); t.hits = int(tab["hits"][i])
             ld = int(tab["last_det"][i])
-            if 0 <= ld < len(dets):       # tracker.py:58-67, 88-90: copy temporal fields when present
+            if clip is not None:          # device path of a temporal head: the detection itself never reached the host
+                if 0 <= ld < clip.n_dets:
+                    t.action_label = clip.label(t.class_id)
+                    t.temporal_score = t.confidence
+                    t.sequence_start_frame, t.sequence_end_frame = clip.start_frame, clip.end_frame
+            elif 0 <= ld < len(dets):     # tracker.py:58-67, 88-90: copy temporal fields when present
                 d = dets[ld]
                 for key in _TEMPORAL_KEYS:
                     if hasattr(d, key):

@@ -262,8 +262,20 @@ def test_host_path_detector_feeds_the_shared_tracker():
     assert clip_tracks[0].track_id == n0 + 1                       # the global counter continues where tick 0 left off; stream 0 first
     assert clip_tracks[0].sequence_end_frame == 1 and clip_tracks[0].temporal_score is not None
     assert r1.detections_emitted["clip"] == 5
-    with pytest.raises(NotImplementedError):
-        PipelinedTicks(pipe)
+    # the same mixed pipeline in throughput mode (temporal head + YOLO group, two ticks in flight): same tables
+    srcs2 = [SyntheticNv12Stream(s, index=i, width=640, height=360, n_unique=2) for i, s in enumerate(streams)]
+    for s in srcs2:
+        s.open_sync()
+    torch.manual_seed(1)
+    clip_det2 = HipCNNLSTMDetector(tcfg_det, net=copy.deepcopy(clip_det.net).float().cpu())
+    trk2 = IouTracker(TrackerConfig(max_age=5, max_iou_distance=0.5, min_hits=1), max_streams=2, capacity=256)
+    runner = PipelinedTicks(TickPipeline(streams, [clip_det2, yolo], trk2, sources=srcs2), depth=2)
+    runner.submit(); runner.submit()
+    q0, q1 = runner.collect_result(), runner.collect_result()
+    assert _tab(q0.tracks["yolo"]) == _tab(r0.tracks["yolo"]) and q0.tracks["clip"] == []
+    assert [(t.track_id, t.class_id, t.action_label, t.sequence_end_frame) for t in q1.tracks["clip"]] == \
+           [(t.track_id, t.class_id, t.action_label, t.sequence_end_frame) for t in clip_tracks]
+    assert q1.detections_emitted == r1.detections_emitted
 
 
 def test_config4_shape_8x4k_cnn_lstm_clips_through_the_pipeline():
@@ -311,3 +323,27 @@ def test_config4_shape_8x4k_cnn_lstm_clips_through_the_pipeline():
     got = first["uhd3"]
     assert [t.class_id for t in got] == top.tolist()
     assert np.allclose([t.confidence for t in got], want[top], atol=1e-3)
+    # throughput mode (two tick chains: the clip pre-process of tick k+1 beside the network of tick k) gives the same tracks
+    srcs2 = [SyntheticNv12Stream(s, index=i, width=3840, height=2160, n_unique=2) for i, s in enumerate(streams)]
+    for s in srcs2:
+        s.open_sync()
+    det2 = HipCNNLSTMDetector(cfg, net=copy.deepcopy(net))
+    trk2 = IouTracker(TrackerConfig(max_age=30, max_iou_distance=0.5, min_hits=1), max_streams=S, capacity=64)
+    runner = PipelinedTicks(TickPipeline(streams, det2, trk2, sources=srcs2), depth=2)
+    assert runner.net_streams == 2 and not runner.use_graph
+    fired2, last = [], None
+    runner.submit()
+    for t in range(1, T + 1):
+        if t < T:
+            runner.submit()
+        r = runner.collect_result()
+        if any(r.detections_emitted.get(n, 0) for n in pipe.names):
+            fired2.append(r.tick)
+            if last is None:
+                last = {n: [(t_.track_id, t_.class_id, t_.action_label, t_.sequence_start_frame, t_.sequence_end_frame) for t_ in v]
+                        for n, v in r.tracks.items()}
+                conf2 = {n: [t_.confidence for t_ in v] for n, v in r.tracks.items()}
+    assert fired2 == fired
+    assert last == {n: [(t_.track_id, t_.class_id, t_.action_label, t_.sequence_start_frame, t_.sequence_end_frame) for t_ in v]
+                    for n, v in first.items()}
+    assert all(np.allclose(conf2[n], [t_.confidence for t_ in first[n]], atol=1e-4) for n in first)
