@@ -674,26 +674,29 @@ def end_to_end_load_sweep(args, sources, rctx, dev, dcfg, tcfg, light_fps):
         ops.postprocess(h.half(), args.conf, args.iou, None, meta, out=post, ctx=rctx)
         return float(post.counts.float().mean().item()), (s0, sr)
 
+    # What the seeded random head can deliver is a staircase, not a dial: its class field is spatially smooth, so the boxes
+    # that clear the threshold come in clusters that NMS merges, until the whole frame lights up.  Scan the candidate
+    # count on a log grid and take, per target, the grid point whose kept count is nearest -- inside a plateau (its
+    # neighbours must not sit on the next step up, a stream whose frame differs a little would land there).
+    grid = np.geomspace(80.0, 5000.0, 36)
+    scan = [kept_for(float(t)) for t in grid]
+    kept_grid = np.array([k for k, _ in scan])
+    print("[bench] load sweep calibration (candidates -> kept per frame): " +
+          " ".join(f"{t:.0f}->{k:.0f}" for t, k in zip(grid, kept_grid)), file=sys.stderr)
     legs = {}
     for want in (64, 256):
-        lo, hi = float(want), 8000.0
         best = None
-        for _ in range(14):                                          # bisect the candidate count that leaves `want` boxes
-            cand = 0.5 * (lo + hi)
-            kept, sh = kept_for(cand)
-            print(f"[bench] load sweep: {cand:.0f} candidates/frame -> {kept:.1f} kept/frame (want {want})", file=sys.stderr)
-            if best is None or abs(kept - want) < abs(best[0] - want):
-                best = (kept, sh, cand)
-            if abs(kept - want) <= 0.08 * want:
-                break
-            if kept > want:
-                hi = cand
-            else:
-                lo = cand
-        kept, shifts, cand = best
-        if abs(kept - want) > 0.5 * want:
-            legs[f"kept{want}"] = {"error": f"calibration reached {kept:.0f} kept per frame only"}
+        for i, k in enumerate(kept_grid):
+            nb = kept_grid[max(i - 1, 0):i + 2]
+            if k < 0.4 * want or k > 2.0 * want or nb.max() > 3.0 * want:
+                continue
+            if best is None or abs(np.log(k / want)) < abs(np.log(kept_grid[best] / want)):
+                best = i
+        if best is None:
+            legs[f"kept{want}"] = {"error": "the seeded head has no stable operating point near this load",
+                                   "reachable_kept_per_frame": sorted({int(k) for k in kept_grid})}
             continue
+        kept, shifts, cand = float(kept_grid[best]), scan[best][1], float(grid[best])
         net = copy.deepcopy(base_net)
         apply_class_shifts(net, *shifts)
         det = HipYoloDetector(dcfg, net=net, device=dev.index)
@@ -705,8 +708,14 @@ def end_to_end_load_sweep(args, sources, rctx, dev, dcfg, tcfg, light_fps):
         trk = IouTracker(tcfg, max_streams=S, capacity=1024, device=dev.index)
         pipe = TickPipeline(streams, det, trk, sources=still)
         runner = PipelinedTicks(pipe, depth=args.depth, use_graph=not args.no_graph)
-        for _ in range(30):
-            runner.submit(); runner.collect()
+        try:
+            for _ in range(30):
+                runner.submit(); runner.collect()
+        except RuntimeError as exc:                                  # a stream fell onto the next step of the staircase
+            legs[f"kept{want}"] = {"error": str(exc), "candidates_per_frame_calibrated": round(cand, 0), "kept_on_the_sample": kept}
+            del runner, pipe, trk, det, still
+            torch.cuda.synchronize()
+            continue
         torch.cuda.synchronize()
         K = 150
         lat, t_enq, rows = np.empty(K), np.empty(K), 0
@@ -720,7 +729,7 @@ def end_to_end_load_sweep(args, sources, rctx, dev, dcfg, tcfg, light_fps):
         rows += sum(t["n"] for t in runner.collect()[1]); lat[K - 1] = time.perf_counter() - t_enq[K - 1]
         el = time.perf_counter() - t0
         fps = S * K / el
-        legs[f"kept{want}"] = {"frames_per_s": round(fps, 1), "ms_per_tick": round(el / K * 1e3, 4),
+        legs[f"kept{want}"] = {"target_kept_per_frame": want, "frames_per_s": round(fps, 1), "ms_per_tick": round(el / K * 1e3, 4),
                                "p99_latency_ms": round(float(np.percentile(lat, 99)) * 1e3, 3),
                                "kept_per_frame": round(float(runner.last_post.counts.float().mean().item()), 1),
                                "candidates_per_frame_calibrated": round(cand, 0), "tracks_per_stream": round(rows / (K * S), 1),

@@ -280,20 +280,23 @@ __global__ void __launch_bounds__(256) k1_ratio_content(K1Args a)
 // ---- general path ----------------------------------------------------------------------------
 // MODE: 0 = detector tensor (letterbox, x 1/255), 1 = clip tensor (stretch, mean/std), 2 = uint8 BGR HWC image
 // (stretch; the `downsample` stage of utils/frame_filter.py:53-57)
-template <bool NV12, int MODE, typename OutT>
+// PX: output pixels per thread.  8 (one 16-byte store per plane) when neighbouring output pixels share source cache lines;
+// 1 for the heavy decimations of the clip heads (4K -> 224: 17 source pixels between two taps, every tap its own sector),
+// where eight times the threads means eight times the loads in flight -- the kernel is latency-bound there, not byte-bound.
+template <bool NV12, int MODE, typename OutT, int PX = 8>
 __global__ void __launch_bounds__(256) k1_generic(K1Args a)
 {
     const int img = blockIdx.y;
-    const int groups = (a.dst_w + 7) >> 3;
+    const int groups = (a.dst_w + PX - 1) / PX;
     const int item = blockIdx.x * 256 + threadIdx.x;
     if (item >= groups * a.dst_h) return;
     const int oy = item / groups, xg = item - oy * groups;
-    const int ox = xg << 3;
-    const int nvalid = a.dst_w - ox < 8 ? a.dst_w - ox : 8;
+    const int ox = xg * PX;
+    const int nvalid = a.dst_w - ox < PX ? a.dst_w - ox : PX;
     const size_t plane = (size_t)a.dst_w * a.dst_h;
     const size_t fstride = MODE == 1 ? (size_t)a.fstride : 3 * plane, cstride = MODE == 1 ? (size_t)a.cstride : plane;
     OutT *out = (OutT *)a.out + (size_t)img * fstride + (size_t)oy * a.dst_w + ox;
-    alignas(16) OutT vr[8], vg[8], vb[8];
+    alignas(16) OutT vr[PX], vg[PX], vb[PX];
     const uint8_t *p0 = a.p0[img];
     const uint8_t *p1 = a.p1[img];
     const int pitch = a.pitch[img];
@@ -319,7 +322,7 @@ __global__ void __launch_bounds__(256) k1_generic(K1Args a)
         }
     };
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < PX; ++i) {
         int b = 114, g = 114, r = 114;
         const int cx = ox + i - a.left;
         if (row_in && cx >= 0 && cx < a.new_w && i < nvalid) {
@@ -352,10 +355,16 @@ __global__ void __launch_bounds__(256) k1_generic(K1Args a)
         }
     }
     if constexpr (MODE == 2) return;
-    const bool vec_ok = (a.dst_w & 7) == 0;
-    store8<OutT>(out, vr, vec_ok, nvalid);
-    store8<OutT>(out + cstride, vg, vec_ok, nvalid);
-    store8<OutT>(out + 2 * cstride, vb, vec_ok, nvalid);
+    if constexpr (PX == 8) {
+        const bool vec_ok = (a.dst_w & 7) == 0;
+        store8<OutT>(out, vr, vec_ok, nvalid);
+        store8<OutT>(out + cstride, vg, vec_ok, nvalid);
+        store8<OutT>(out + 2 * cstride, vb, vec_ok, nvalid);
+    } else {
+#pragma unroll
+        for (int i = 0; i < PX; ++i)
+            if (i < nvalid) { out[i] = vr[i]; out[cstride + i] = vg[i]; out[2 * cstride + i] = vb[i]; }
+    }
 }
 
 // kernel launch with optional start / stop events written by the dispatch itself (hipExtLaunchKernelGGL): the pair
@@ -501,7 +510,9 @@ int preprocess_common(rva_ctx *ctx, bool nv12, int mode, const void *const *p0, 
     a.yofs = ty.ofs; a.yw0 = ty.w0; a.yw1 = ty.w1;
     if (mode != 2 && !out_aligned && (dst_w % 8 == 0))  // vector stores need 16-byte rows
         return rva_fail(ctx, RVA_ERR_ARG, "output tensor must be 16-byte aligned");
-    dim3 grid(rva_ceil_div(rva_ceil_div(dst_w, 8) * dst_h, 256), n);
+    // clip heads at heavy decimation (4K -> 224 x 224): one output pixel per thread
+    const bool px1 = mode == 1 && out_dtype != RVA_F64 && (long)src_w >= 4L * dst_w;
+    dim3 grid(rva_ceil_div(rva_ceil_div(dst_w, px1 ? 1 : 8) * dst_h, 256), n);
     // one-shot profiling events (rva_profile_next_preprocess) bracket the generic kernel too
     hipEvent_t ge0 = ctx->k1_start, ge1 = ctx->k1_stop;
     ctx->k1_start = ctx->k1_stop = nullptr;
@@ -515,17 +526,29 @@ int preprocess_common(rva_ctx *ctx, bool nv12, int mode, const void *const *p0, 
         if (out_dtype == RVA_F16) RVA_LAUNCH_GENERIC_T(NV, MD, __half);                    \
         else RVA_LAUNCH_GENERIC_T(NV, MD, float);                                          \
     } while (0)
+#define RVA_LAUNCH_CLIP1(NV)                                                                                       \
+    do {                                                                                                           \
+        if (out_dtype == RVA_F16) {                                                                                \
+            if (ge0 && ge1) hipExtLaunchKernelGGL((k1_generic<NV, 1, __half, 1>), grid, dim3(256), 0, stream, ge0, ge1, 0, a); \
+            else k1_generic<NV, 1, __half, 1><<<grid, 256, 0, stream>>>(a);                                        \
+        } else {                                                                                                   \
+            if (ge0 && ge1) hipExtLaunchKernelGGL((k1_generic<NV, 1, float, 1>), grid, dim3(256), 0, stream, ge0, ge1, 0, a);  \
+            else k1_generic<NV, 1, float, 1><<<grid, 256, 0, stream>>>(a);                                         \
+        }                                                                                                          \
+    } while (0)
     if (mode == 2) { if (nv12) RVA_LAUNCH_GENERIC(true, 2); else RVA_LAUNCH_GENERIC(false, 2); }
     else if (clip && out_dtype == RVA_F64) {
         if (nv12) RVA_LAUNCH_GENERIC_T(true, 1, double);
         else RVA_LAUNCH_GENERIC_T(false, 1, double);
     }
+    else if (px1) { if (nv12) RVA_LAUNCH_CLIP1(true); else RVA_LAUNCH_CLIP1(false); }
     else if (nv12 && clip) RVA_LAUNCH_GENERIC(true, 1);
     else if (nv12) RVA_LAUNCH_GENERIC(true, 0);
     else if (clip) RVA_LAUNCH_GENERIC(false, 1);
     else RVA_LAUNCH_GENERIC(false, 0);
 #undef RVA_LAUNCH_GENERIC
 #undef RVA_LAUNCH_GENERIC_T
+#undef RVA_LAUNCH_CLIP1
     RVA_HIP(ctx, hipGetLastError());
     return RVA_OK;
 }

@@ -294,6 +294,9 @@ class FusedYoloV8:
         self._conv(net.b5, p3, t4, h3, w3)
         self._c2f(net.b6, t4, p4, h4, w4)
         t5 = _View(self._buf(B * h5 * w5, c5), 0, c5)
+        # from here on the backbone works at 20x20 (b7, b8, SPPF): a quarter of a millisecond in which most CUs and most of
+        # the HBM bandwidth are idle -- a pipelined runner may start the NEXT tick's K1 here (``phase_event``)
+        self.quiet_step = len(self._steps)
         self._conv(net.b7, p4, t5, h4, w4)
         t5b = _View(self._buf(B * h5 * w5, c5), 0, c5)
         self._c2f(net.b8, t5, t5b, h5, w5)
@@ -560,7 +563,10 @@ class FusedYoloV8:
         main = torch.cuda.current_stream()
         stream = C.c_void_p(main.cuda_stream)
         if not (self.concurrent_heads and self._forks):
-            for step in self._steps:
+            ev = getattr(self, "phase_event", None)
+            for i, step in enumerate(self._steps):
+                if ev is not None and i == self.quiet_step:
+                    ev.record(main)                        # the pass enters its 20x20 phase
                 step(stream)
             return self.out
         # fork / join over events: works eagerly and inside a stream capture (the side streams join the capture through

@@ -435,6 +435,10 @@ class PipelinedTicks:
             self.sAs = [torch.cuda.Stream(device=self.det.device), torch.cuda.Stream(device=self.det.device)]
         else:
             self.sAs = [self.sA, self.sA]
+        # K1 of tick k+1 beside the 20x20 phase of tick k's forward pass (most CUs and most of the HBM bandwidth idle there)
+        # instead of beside its stem / 80x80 layers: RVA_K1_GATE=1.  Off by default: see DESIGN.md (K1 in the pipeline).
+        self.k1_gate = os.environ.get("RVA_K1_GATE", "0") == "1" and self.net_streams == 2
+        self._phase_ev = [torch.cuda.Event(), torch.cuda.Event()]
         self._pending = [None, None]          # per parity: what the stream-B part of that tick needs
         self._meta = [None, None]             # per parity: (packets, t0) for collect_result
         self._next, self._oldest = 0, 0
@@ -566,6 +570,8 @@ class PipelinedTicks:
                     sk.wait_event(self._k1_done[par ^ 1])          # the previous tick's K5 / K1 (gate state, source rings) first
                 if k >= 2:
                     sk.wait_event(self._net_done[par])             # tick k-2's network has read the input tensors of this slot
+                if self.k1_gate and k >= 1:
+                    sk.wait_event(self._phase_ev[par ^ 1])         # ... and tick k-1's forward pass has reached its 20x20 phase
             packets = p._frames_for_detection(packets)             # roi / downsample (device work)
             plan = p.plan_tick(packets, process)
             motion = p._device_gates(packets, par) if p.has_gates else None       # K5 + gate parameters (no sync)
@@ -593,7 +599,9 @@ class PipelinedTicks:
                 else:
                     with torch.inference_mode():
                         if plan_det and self.two_streams:
-                            self._plan_of(det, pre[0]).use_output(gi if self.net_streams == 2 else 2 * gi + par)
+                            fp = self._plan_of(det, pre[0])
+                            fp.use_output(gi if self.net_streams == 2 else 2 * gi + par)
+                            fp.phase_event = self._phase_ev[par] if (self.k1_gate and gi == 0) else None
                         elif plan_det:
                             self._plan_of(det, pre[0])             # sets the plan's branch mode for this runner's layout
                         raws.append(det.stage_net(pre))
