@@ -637,85 +637,33 @@ def extras(args, out, sources, rctx, dev, dcfg, tcfg):
 
 
 def end_to_end_load_sweep(args, sources, rctx, dev, dcfg, tcfg, light_fps):
-    """Frames/s of the WHOLE pipeline (same runner, same streams) with the synthetic head re-calibrated so that about 64 and
-    about 256 boxes per frame survive NMS -- the headline scene keeps ~13.  The class-bias shifts are bisected on the heads of
-    8 sample frames pushed through K2/K3 (boxes of the fused plan + shifted class probabilities), then a fresh detector /
-    tracker / runner is timed for 150 ticks after 30 warm-up ticks.  The scene of these legs is STATIC (every stream shows
-    one frame over and over): the detections repeat, every track is matched every tick, so tracks per stream ~ boxes kept
-    per frame and K4 sees D detections x D tracks -- the load the sweep is named for.  (With the two alternating frames of
-    the headline run and these random-weight heads, tracks churn and pile up for max_age = 30 ticks: an unbounded table in
-    the reference, an overflow error here.)"""
+    """Frames/s of the WHOLE pipeline (same streams, same runner, the network running in full) with the tail under load: K2
+    reads a PLANTED head -- the synthetic heads of `post_tracker_load_sweep`, 64 and 256 objects per frame -- instead of the
+    network's own output, whose seeded random weights keep ~13 boxes per frame.  Why planted: the class field of a random
+    head is spatially smooth, so what survives NMS is a staircase in the calibration knob (6, 12, 113, 1731 boxes per frame
+    on this scene), not a dial.  Everything else is the headline pipeline: K1, every layer of the detector, K2 (same
+    tensor shape, from another buffer), K3, K4, ids, snapshot; 150 timed ticks after 30 warm-up ticks per leg."""
     import copy
-    from realtime_video_analytics_32streams_amd import _native as N
-    from realtime_video_analytics_32streams_amd import ops
+    from realtime_video_analytics_32streams_amd import ops, synth
     from realtime_video_analytics_32streams_amd.config import StreamConfig
     from realtime_video_analytics_32streams_amd.detector import HipYoloDetector
-    from realtime_video_analytics_32streams_amd.engine import FusedYoloV8
     from realtime_video_analytics_32streams_amd.pipeline import PipelinedTicks, TickPipeline
     from realtime_video_analytics_32streams_amd.tracker import IouTracker
-    from realtime_video_analytics_32streams_amd.video_stream import SyntheticNv12Stream
-    from realtime_video_analytics_32streams_amd.yolov8 import apply_class_shifts, build_detector_net, density_shifts
+    from realtime_video_analytics_32streams_amd.yolov8 import build_detector_net
     S = len(sources)
     base_net = build_detector_net(args.model, seed=0)
-    meta = [N.letterbox(args.width, args.height, 640, 640)]
-    with torch.inference_mode():
-        sample, _ = ops.preprocess_nv12([src._ring[0] for src in sources[:8]], (640, 640), half=True, ctx=rctx)
-        head = FusedYoloV8(copy.deepcopy(base_net).fuse().half().to(dev), sample.shape[0], device=dev, ctx=rctx, autotune=False)(sample.contiguous()).float()
-    probs = head[:, 4:, :].clamp(2.0 ** -20, 1.0 - 2.0 ** -11)
-    z = torch.log(probs / (1.0 - probs))
-    post = ops.PostBuffers.allocate(head.shape[0], head.shape[2], dev)
-
-    def kept_for(target):
-        q = 1.0 - min(0.6, max(0.05, 3.0 * target / head.shape[2]))
-        s0, sr = density_shifts(z, args.conf, target, objectness_quantile=q)
-        h = head.clone()
-        h[:, 4] = torch.sigmoid(z[:, 0] + s0)
-        h[:, 5:] = torch.sigmoid(z[:, 1:] + sr)
-        ops.postprocess(h.half(), args.conf, args.iou, None, meta, out=post, ctx=rctx)
-        return float(post.counts.float().mean().item()), (s0, sr)
-
-    # What the seeded random head can deliver is a staircase, not a dial: its class field is spatially smooth, so the boxes
-    # that clear the threshold come in clusters that NMS merges, until the whole frame lights up.  Scan the candidate
-    # count on a log grid and take, per target, the grid point whose kept count is nearest -- inside a plateau (its
-    # neighbours must not sit on the next step up, a stream whose frame differs a little would land there).
-    grid = np.geomspace(80.0, 5000.0, 36)
-    scan = [kept_for(float(t)) for t in grid]
-    kept_grid = np.array([k for k, _ in scan])
-    print("[bench] load sweep calibration (candidates -> kept per frame): " +
-          " ".join(f"{t:.0f}->{k:.0f}" for t, k in zip(grid, kept_grid)), file=sys.stderr)
+    streams = [StreamConfig(name=src.config.name, url=src.config.url, target_fps=30.0, warmup_seconds=0.0) for src in sources]
     legs = {}
-    for want in (64, 256):
-        best = None
-        for i, k in enumerate(kept_grid):
-            nb = kept_grid[max(i - 1, 0):i + 2]
-            if k < 0.4 * want or k > 2.0 * want or nb.max() > 3.0 * want:
-                continue
-            if best is None or abs(np.log(k / want)) < abs(np.log(kept_grid[best] / want)):
-                best = i
-        if best is None:
-            legs[f"kept{want}"] = {"error": "the seeded head has no stable operating point near this load",
-                                   "reachable_kept_per_frame": sorted({int(k) for k in kept_grid})}
-            continue
-        kept, shifts, cand = float(kept_grid[best]), scan[best][1], float(grid[best])
-        net = copy.deepcopy(base_net)
-        apply_class_shifts(net, *shifts)
-        det = HipYoloDetector(dcfg, net=net, device=dev.index)
-        streams = [StreamConfig(name=src.config.name, url=src.config.url, target_fps=30.0, warmup_seconds=0.0) for src in sources]
-        still = [SyntheticNv12Stream(st, index=src.index, width=src.width, height=src.height, n_unique=1, device=dev)
-                 for st, src in zip(streams, sources)]
-        for src in still:
-            src.open_sync()
+    for D in (64, 256):
+        planted = torch.from_numpy(synth.make_head_batch([9000 + D + i for i in range(S)], layout="CA", n_obj=D)).to(dev).half()
+        det = HipYoloDetector(dcfg, net=copy.deepcopy(base_net), device=dev.index)
+        own_post = det.stage_post
+        det.stage_post = lambda raw, pre, own_post=own_post, planted=planted: own_post(planted, pre)   # the network ran; K2 reads the planted head
         trk = IouTracker(tcfg, max_streams=S, capacity=1024, device=dev.index)
-        pipe = TickPipeline(streams, det, trk, sources=still)
+        pipe = TickPipeline(streams, det, trk, sources=sources)
         runner = PipelinedTicks(pipe, depth=args.depth, use_graph=not args.no_graph)
-        try:
-            for _ in range(30):
-                runner.submit(); runner.collect()
-        except RuntimeError as exc:                                  # a stream fell onto the next step of the staircase
-            legs[f"kept{want}"] = {"error": str(exc), "candidates_per_frame_calibrated": round(cand, 0), "kept_on_the_sample": kept}
-            del runner, pipe, trk, det, still
-            torch.cuda.synchronize()
-            continue
+        for _ in range(30):
+            runner.submit(); runner.collect()
         torch.cuda.synchronize()
         K = 150
         lat, t_enq, rows = np.empty(K), np.empty(K), 0
@@ -729,13 +677,14 @@ def end_to_end_load_sweep(args, sources, rctx, dev, dcfg, tcfg, light_fps):
         rows += sum(t["n"] for t in runner.collect()[1]); lat[K - 1] = time.perf_counter() - t_enq[K - 1]
         el = time.perf_counter() - t0
         fps = S * K / el
-        legs[f"kept{want}"] = {"target_kept_per_frame": want, "frames_per_s": round(fps, 1), "ms_per_tick": round(el / K * 1e3, 4),
-                               "p99_latency_ms": round(float(np.percentile(lat, 99)) * 1e3, 3),
-                               "kept_per_frame": round(float(runner.last_post.counts.float().mean().item()), 1),
-                               "candidates_per_frame_calibrated": round(cand, 0), "tracks_per_stream": round(rows / (K * S), 1),
-                               "vs_light_load": round(fps / light_fps, 4)}
-        del runner, pipe, trk, det, still
-    return {"streams": S, "ticks": 150, "scene": "static (one frame per stream, repeated)", "light_load_frames_per_s": light_fps, **legs}
+        legs[f"D{D}"] = {"planted_objects_per_frame": D, "frames_per_s": round(fps, 1), "ms_per_tick": round(el / K * 1e3, 4),
+                         "p99_latency_ms": round(float(np.percentile(lat, 99)) * 1e3, 3),
+                         "candidates_per_frame": round(float(runner.last_post.ncand.float().mean().item()), 0),
+                         "kept_per_frame": round(float(runner.last_post.counts.float().mean().item()), 1),
+                         "tracks_per_stream": round(rows / (K * S), 1), "vs_light_load": round(fps / light_fps, 4)}
+        del runner, pipe, trk, det, planted
+    return {"streams": S, "ticks": 150, "light_load_frames_per_s": light_fps,
+            "note": "the network runs in full; K2 reads a planted head (see the docstring of end_to_end_load_sweep)", **legs}
 
 
 def decode_stage(dev):

@@ -60,14 +60,9 @@ static void free_post(rva_ctx *ctx)
     (void)hipFree(ctx->sp_box);
     (void)hipFree(ctx->sp_score);
     (void)hipFree(ctx->sp_cls);
-    (void)hipFree(ctx->cand_list);
-    (void)hipFree(ctx->cand_count);
     (void)hipFree(ctx->cand_bits);
-    (void)hipFree(ctx->k3_state); (void)hipFree(ctx->k3_anchor); (void)hipFree(ctx->k3_box); (void)hipFree(ctx->k3_mask);
-    (void)hipFree(ctx->k3_wprefix);
-    ctx->k3_state = ctx->k3_anchor = ctx->k3_wprefix = nullptr; ctx->k3_box = nullptr; ctx->k3_mask = nullptr; ctx->k3_km = 0;
     ctx->sp_box = ctx->sp_score = nullptr;
-    ctx->sp_cls = ctx->cand_list = ctx->cand_count = nullptr;
+    ctx->sp_cls = nullptr;
     ctx->cand_bits = nullptr;
     ctx->cap_batch = ctx->cap_anchors = 0;
 }
@@ -98,18 +93,7 @@ int rva_reserve(rva_ctx *ctx, int batch, int anchors)
     RVA_HIP(ctx, hipMalloc(&ctx->sp_box, ba * 4 * sizeof(float)));
     RVA_HIP(ctx, hipMalloc(&ctx->sp_score, ba * sizeof(float)));
     RVA_HIP(ctx, hipMalloc(&ctx->sp_cls, ba * sizeof(int32_t)));
-    RVA_HIP(ctx, hipMalloc(&ctx->cand_list, ba * sizeof(int32_t)));
-    RVA_HIP(ctx, hipMalloc(&ctx->cand_count, (size_t)b * sizeof(int32_t)));
     RVA_HIP(ctx, hipMalloc(&ctx->cand_bits, (size_t)b * rva_ceil_div(a, 32) * sizeof(uint32_t) + 8));
-    // suppression-bitmask scratch of K3: km candidates per image (2 MiB of mask per image at km = 4096)
-    int km = ((a < 4096 ? a : 4096) + 63) & ~63;
-    RVA_HIP(ctx, hipMalloc(&ctx->k3_state, (size_t)b * sizeof(int32_t)));
-    RVA_HIP(ctx, hipMemset(ctx->k3_state, 0, (size_t)b * sizeof(int32_t)));
-    RVA_HIP(ctx, hipMalloc(&ctx->k3_anchor, (size_t)b * km * sizeof(int32_t)));
-    RVA_HIP(ctx, hipMalloc(&ctx->k3_box, (size_t)b * km * 4 * sizeof(float)));
-    RVA_HIP(ctx, hipMalloc(&ctx->k3_mask, (size_t)b * km * (km / 64) * sizeof(unsigned long long)));
-    RVA_HIP(ctx, hipMalloc(&ctx->k3_wprefix, (size_t)b * rva_ceil_div(a, 32) * sizeof(int32_t)));
-    ctx->k3_km = km;
     ctx->cap_batch = b;
     ctx->cap_anchors = a;
     return RVA_OK;

@@ -31,17 +31,8 @@ struct rva_ctx {
     float *sp_box = nullptr;      // [B][A][4] xyxy of thresholded anchors (sparse, anchor-indexed)
     float *sp_score = nullptr;    // [B][A]
     int32_t *sp_cls = nullptr;    // [B][A]
-    int32_t *cand_list = nullptr; // [B][A] anchors that passed, unordered
-    int32_t *cand_count = nullptr;// [B]
     uint32_t *cand_bits = nullptr;// [B][ceil(A/32)] pass bitmap in anchor order
     int32_t *post_flags = nullptr;// [1]
-    // K3 under load: suppression-bitmask path (images with more than K3_SMALL and at most k3_km sorted candidates)
-    int k3_km = 0;                // candidates per image the mask path holds (multiple of 64, <= 4096)
-    int32_t *k3_state = nullptr;  // [B] number of sorted candidates handed to the mask path (0 = image finished in k3_nms)
-    int32_t *k3_anchor = nullptr; // [B][km] anchors in NMS order (score desc, anchor asc)
-    float *k3_box = nullptr;      // [B][km][4] their boxes
-    unsigned long long *k3_mask = nullptr;   // [B][km][km/64] bit j of word w of row i: box 64w+j (> i) is suppressed by box i
-    int32_t *k3_wprefix = nullptr;// [B][ceil(A/32)] passing anchors before bitmap word w (the `keep` index of a survivor)
     // resize tap tables keyed by (src, dst) per axis
     std::map<uint64_t, rva_resize_table> taps_x, taps_y;
     // one-shot profiling events for the next K1 (integer-ratio) launch: rva_profile_next_preprocess

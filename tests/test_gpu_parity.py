@@ -93,13 +93,14 @@ def test_postprocess_worst_case_every_anchor_is_a_candidate():
     assert np.array_equal(got["boxes"], want["boxes"]) and np.array_equal(got["conf"], want["conf"])
 
 
-def test_postprocess_busy_images_take_the_suppression_matrix_path():
-    """Images with 129 ... 4096 sorted candidates leave k3_nms after the sort (k3_mask builds the suppression matrix on all
-    CUs, k3_reduce replays the greedy loop over it); 128 and fewer, and more than 4096, finish inside k3_nms.  One batch with
-    candidate counts on both sides of both limits, chunk-boundary counts included; every image against the oracle."""
+def test_postprocess_busy_images_across_sort_sizes_and_nms_rounds():
+    """Busy images: K3 sorts 512 ... 8192 keys in registers (1 ... 16 keys per thread) and runs greedy NMS in rounds of 512
+    sorted boxes (phase 1 against the boxes kept so far, phase 2 the survivors among themselves on a suppression matrix
+    in LDS).  One batch with candidate counts on both sides of the sort sizes, of the 64-survivor chunks and of the
+    512-box rounds; every image against the oracle, at a threshold with few and one with many survivors per round."""
     rng = np.random.default_rng(11)
     A = 8400
-    counts = [128, 129, 191, 192, 193, 1000, 2500, 4095, 4096, 4097, 0, 64]
+    counts = [128, 129, 191, 192, 193, 511, 512, 513, 1000, 1025, 2500, 4095, 4096, 4097, 0, 64]
     heads = np.zeros((len(counts), 84, A), np.float32)
     for b, k in enumerate(counts):
         p = np.zeros((A, 84), np.float32)
