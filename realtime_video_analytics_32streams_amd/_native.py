@@ -17,7 +17,7 @@ from typing import Optional
 PKG = Path(__file__).resolve().parent
 ROOT = PKG.parent
 CSRC = PKG / "csrc"
-LIB_PATH = PKG / "librva.so"
+LIB_PATH = Path(os.environ["RVA_LIB_PATH"]) if os.environ.get("RVA_LIB_PATH") else PKG / "librva.so"   # override: diagnostic builds (tools/)
 SOURCES = ["rva_ctx.hip", "rva_preprocess.hip", "rva_postprocess.hip", "rva_tracker.hip", "rva_conv.hip", "rva_gates.hip",
            "rva_decode.hip", "rva_preview.hip"]
 # -ffp-contract=off: parity kernels must not fuse a*b+c (SURVEY.md hard part 4)

@@ -26,6 +26,9 @@
 //         K x kept + survivors^2 / 2 IoUs instead of the K^2 / 2 of a full suppression matrix.
 #include <hip/hip_fp16.h>
 
+#include <cmath>
+#include <cstring>
+
 #include "rva_internal.h"
 
 namespace {
@@ -116,6 +119,28 @@ __device__ __forceinline__ float iou32(const float4 a, const float4 b)
     return __fdiv_rn(inter, uni);
 }
 
+// `!(iou32(a, b) <= thr)` without the division.  q = RN(inter / u) is monotonic in the real quotient, so q <= thr exactly when
+// inter / u does not exceed the point where rounding leaves thr: the midpoint m of thr and the next float above it, itself
+// included when a tie rounds to thr (thr's mantissa even), excluded otherwise.  m has 25 significant bits and u 24: the
+// double product m * u is exact, and so is the comparison.  NaN operands make every comparison false -> suppressed, as a NaN
+// quotient does in the reference's `iou <= thr` (detector.py:373).  Same float32 operations as iou32() up to u.
+struct SupTest { double m; int tie_incl; };
+
+__device__ __forceinline__ bool suppresses(const float4 a, const float area_a, const float4 b, const float area_b, const SupTest t)
+{
+    const float x1 = fmaxf(a.x, b.x), y1 = fmaxf(a.y, b.y);
+    const float x2 = fminf(a.z, b.z), y2 = fminf(a.w, b.w);
+    float w = x2 - x1, h = y2 - y1;
+    w = w > 0.0f ? w : 0.0f;
+    h = h > 0.0f ? h : 0.0f;
+    const float inter = w * h;
+    float uni = area_a + area_b - inter;
+    uni = fmaxf(uni, 1e-6f);
+    const double di = (double)inter, rhs = t.m * (double)uni;
+    return !(t.tie_incl ? di <= rhs : di < rhs);
+}
+__device__ __forceinline__ float box_area(const float4 b) { return (b.z - b.x) * (b.w - b.y); }
+
 struct K3Args {
     const float4 *sp_box;
     const float *sp_score;
@@ -124,6 +149,7 @@ struct K3Args {
     int nwords, A, kcap;  // kcap: power of two, LDS key capacity
     int sc;               // super-chunk: boxes per NMS round (512, or 256 when the keys take 128 KB of LDS)
     float iou_thr;
+    SupTest sup;          // the same decision as `!(iou <= iou_thr)`, division-free (see suppresses())
     int max_det;
     float4 *out_boxes;
     float *out_scores;
@@ -131,7 +157,16 @@ struct K3Args {
     int32_t *flags;
 };
 
-constexpr int K3_THREADS = 512;
+#ifdef RVA_K3_STAMPS
+// diagnostic build only (tools/k3_stamps.py): s_memtime sums per phase, written by thread 0 of every block
+__device__ unsigned long long g_k3_stamps[64][8];
+#define K3_STAMP(slot) do { if (tid == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[slot] += t_ - st_last; st_last = t_; } } while (0)
+#else
+#define K3_STAMP(slot) do { } while (0)
+#endif
+
+constexpr int K3_THREADS = 1024;   // 16 waves: four per SIMD hide the LDS / ALU latencies of the IoU loops (two did not)
+constexpr int K3_WAVES = K3_THREADS / 64;
 constexpr int K3_KBL = 1024;       // kept boxes held in LDS for phase 1 (further ones are read back from out_boxes)
 
 extern __shared__ __attribute__((aligned(16))) unsigned char k3_smem[];
@@ -216,9 +251,13 @@ __global__ void __launch_bounds__(K3_THREADS) k3_nms(K3Args a)
     int *sv_j = (int *)(k3_smem + off); off += (size_t)SC * 4;              // their position in the sorted list
     unsigned long long *smask = (unsigned long long *)(k3_smem + off); off += (size_t)SC * (SC / 64) * 8;   // [SC][SC/64]
     int *wprefix = (int *)(k3_smem + off); off += (((size_t)a.nwords * 4 + 15) & ~(size_t)15);             // [nwords]
-    int *wave_tot = (int *)(k3_smem + off); off += 64;                       // [8]
+    int *wave_tot = (int *)(k3_smem + off); off += 64;                       // [16]
+    unsigned long long *half_alive = (unsigned long long *)(k3_smem + off); off += 128;   // [16] phase-1 ballots of the two halves
     int *s_ctl = (int *)(k3_smem + off);                                     // [0] survivors, [1] kept so far, [2] scan carry, [3] K
 
+#ifdef RVA_K3_STAMPS
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
+#endif
     // ---- candidates = set bits of the pass bitmap: exclusive prefix of the word popcounts (512 words per round)
     const uint32_t *bw = a.bits + (long)b * a.nwords;
     if (tid == 0) { s_ctl[1] = 0; s_ctl[2] = 0; }
@@ -271,57 +310,93 @@ __global__ void __launch_bounds__(K3_THREADS) k3_nms(K3Args a)
         }
     }
     __syncthreads();
+    K3_STAMP(0);
     switch (Kpad / K3_THREADS) {
     case 1: k3_sort<1>(keys, tid); break;
     case 2: k3_sort<2>(keys, tid); break;
     case 4: k3_sort<4>(keys, tid); break;
     case 8: k3_sort<8>(keys, tid); break;
-    case 16: k3_sort<16>(keys, tid); break;
-    default: k3_sort<32>(keys, tid); break;
+    default: k3_sort<16>(keys, tid); break;
     }
 
+    K3_STAMP(1);
     const int scw = SC >> 6;                                       // mask words per survivor row
     for (int base = 0; base < K; base += SC) {
-        // ---- phase 1: this thread's box against everything kept so far
-        const int j = base + tid;
-        const bool valid = tid < SC && j < K;
+        // ---- phase 1: a box against everything kept so far; two threads per box (t and t + 512) share the kept list
+        // (even / odd groups of four)
+        const int bt = tid & (K3_THREADS / 2 - 1), half = tid / (K3_THREADS / 2);
+        const int j = base + bt;
+        const bool valid = bt < SC && j < K;
         const int an = valid ? (int)(uint32_t)keys[j] : 0;
         const float4 bx = valid ? box[an] : make_float4(0.f, 0.f, 0.f, 0.f);
         bool alive = valid;
         const int nk = s_ctl[1] < a.max_det ? s_ctl[1] : a.max_det;
-        const float4 *kept_glb = a.out_boxes + (long)b * a.max_det;
-        for (int i = 0; i < nk; ++i) {
+        const int nk_lds = nk < K3_KBL ? nk : K3_KBL;
+        // four kept boxes per step, branch-free: the (broadcast) LDS reads and the four tests of a step overlap, one
+        // early-exit test per step
+        const float area_b = box_area(bx);
+        for (int i = 4 * half; i < nk_lds; i += 8) {
             if (!__any(alive)) break;
-            const float4 kbx = i < K3_KBL ? kb[i] : kept_glb[i];
-            if (alive && !(iou32(kbx, bx) <= a.iou_thr)) alive = false;     // detector.py:373
+            float4 k4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) k4[u] = kb[i + u < nk_lds ? i + u : i];        // a repeated box changes nothing
+            bool hit = false;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) hit |= suppresses(k4[u], box_area(k4[u]), bx, area_b, a.sup);     // detector.py:373
+            alive = alive && !hit;
         }
-        // ---- survivors, compacted in sorted order
-        const unsigned long long am = __ballot(alive);
-        if (lane == 0) wave_tot[wave] = __popcll(am);
+        const float4 *kept_glb = a.out_boxes + (long)b * a.max_det;
+        for (int i = K3_KBL + half; i < nk; i += 2) {             // more than 1024 boxes kept in one image: the rest from HBM
+            if (!__any(alive)) break;
+            const float4 kg = kept_glb[i];
+            alive = alive && !suppresses(kg, box_area(kg), bx, area_b, a.sup);
+        }
+        K3_STAMP(2);
+        // ---- survivors (alive in BOTH halves of the kept list), compacted in sorted order by the lower 512 threads
+        const unsigned long long am0 = __ballot(alive);
+        if (lane == 0) half_alive[wave] = am0;
+        __syncthreads();
+        const unsigned long long am = half_alive[wave & (K3_WAVES / 2 - 1)] & half_alive[(wave & (K3_WAVES / 2 - 1)) + K3_WAVES / 2];
+        alive = half == 0 && ((am >> lane) & 1ull);
+        if (lane == 0) wave_tot[wave] = half == 0 ? __popcll(am) : 0;
         __syncthreads();
         int so = 0, ns = 0;
-        for (int q = 0; q < K3_THREADS / 64; ++q) { if (q < wave) so += wave_tot[q]; ns += wave_tot[q]; }
+        for (int q = 0; q < K3_WAVES / 2; ++q) { if (q < wave) so += wave_tot[q]; ns += wave_tot[q]; }
         if (alive) {
             const int sidx = so + __popcll(am & ((1ull << lane) - 1ull));
             sv_box[sidx] = bx;
             sv_j[sidx] = j;
         }
         __syncthreads();
+        K3_STAMP(3);
         if (ns == 0) continue;                                    // uniform
         // ---- phase 2a: suppression matrix of the survivors (row r suppresses column c > r), tiles outer, rows inner
         const int nct = (ns + 63) >> 6;
         for (int ct = 0; ct < nct; ++ct) {
             const int col = ct * 64 + lane;
             const float4 cb = col < ns ? sv_box[col] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float area_c = box_area(cb);
             const int rend = (ct + 1) * 64 < ns ? (ct + 1) * 64 : ns;
-            for (int r = wave; r < rend; r += K3_THREADS / 64) {
-                const float4 rb = sv_box[r];                       // one address for the wave: a broadcast read
-                const bool sup = col < ns && col > r && !(iou32(rb, cb) <= a.iou_thr);
-                const unsigned long long w = __ballot(sup);
-                if (lane == 0) smask[(size_t)r * scw + ct] = w;
+            for (int r0 = wave; r0 < rend; r0 += 4 * K3_WAVES) {               // four rows per step (reads in flight together)
+                float4 rb[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int r = r0 + u * K3_WAVES;
+                    rb[u] = sv_box[r < rend ? r : r0];             // one address for the wave: a broadcast read
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int r = r0 + u * K3_WAVES;
+                    if (r < rend) {                                // wave-uniform
+                        const bool sup = col < ns && col > r && suppresses(rb[u], box_area(rb[u]), cb, area_c, a.sup);
+                        const unsigned long long w = __ballot(sup);
+                        if (lane == 0) smask[(size_t)r * scw + ct] = w;
+                    }
+                }
             }
         }
         __syncthreads();
+        K3_STAMP(4);
         // ---- phase 2b: the greedy loop on the matrix, one wave; lane w keeps the removed word of survivor chunk w
         if (wave == 0) {
             unsigned long long removed = 0ull;
@@ -339,10 +414,15 @@ __global__ void __launch_bounds__(K3_THREADS) k3_nms(K3Args a)
                     al &= ~(1ull << l);
                 }
                 unsigned long long k2 = kept;
-                while (k2) {                                       // kept rows suppress survivors of later chunks
-                    const int l = __builtin_ctzll(k2);
-                    k2 &= k2 - 1ull;
-                    if (lane > c && lane < nct) removed |= smask[(size_t)(c * 64 + l) * scw + lane];
+                const bool later = lane > c && lane < nct;
+                while (k2) {                                       // kept rows suppress survivors of later chunks (four reads in flight)
+                    int l4[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { l4[q] = k2 ? __builtin_ctzll(k2) : -1; if (k2) k2 &= k2 - 1ull; }
+                    unsigned long long r4[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) r4[q] = (l4[q] >= 0 && later) ? smask[(size_t)(c * 64 + l4[q]) * scw + lane] : 0ull;
+                    removed |= r4[0] | r4[1] | r4[2] | r4[3];
                 }
                 if ((kept >> lane) & 1ull) {
                     const int pos = out0 + __popcll(kept & ((1ull << lane) - 1ull));
@@ -368,10 +448,14 @@ __global__ void __launch_bounds__(K3_THREADS) k3_nms(K3Args a)
             if (lane == 0) s_ctl[1] = out0;
         }
         __syncthreads();
+        K3_STAMP(5);
     }
     if (tid == 0) {
         const int n = s_ctl[1];
         a.out_counts[b] = n < a.max_det ? n : a.max_det;
+#ifdef RVA_K3_STAMPS
+        if (b < 64) for (int q = 0; q < 8; ++q) g_k3_stamps[b][q] = st_acc[q];
+#endif
     }
 }
 
@@ -411,9 +495,10 @@ extern "C" int rva_postprocess_batch(rva_ctx *ctx, const void *raw, int raw_dtyp
     int kcap = K3_THREADS;
     while (kcap < A && kcap < 16384) kcap <<= 1;
     const int nwords = rva_ceil_div(A, 32);
-    const int sc = kcap <= 8192 ? 512 : 256;                       // 128 KB of keys leave room for a 256-box round only
+    const int sc = kcap <= 8192 ? 512 : 256;                       // 128 KB of keys leave room for a 256-box round only (sc <= 512:
+                                                                   // two threads per box in phase 1)
     const size_t smem = (size_t)kcap * 8 + (size_t)K3_KBL * 16 + (size_t)sc * 20 + (size_t)sc * (sc / 64) * 8 +
-                        (((size_t)nwords * 4 + 15) & ~(size_t)15) + 64 + 64;
+                        (((size_t)nwords * 4 + 15) & ~(size_t)15) + 64 + 128 + 64;
     if (smem > 160 * 1024) return rva_fail(ctx, RVA_ERR_CAPACITY, "post-process: %d anchors need %zu B of LDS", A, smem);
     RVA_HIP(ctx, rva_func_smem((const void *)k3_nms, smem));
 
@@ -446,6 +531,13 @@ extern "C" int rva_postprocess_batch(rva_ctx *ctx, const void *raw, int raw_dtyp
         k3.bits = ctx->cand_bits;
         k3.nwords = nwords; k3.A = A; k3.kcap = kcap; k3.sc = sc;
         k3.iou_thr = (float)iou_thr;
+        {   // where rounding leaves thr: midpoint to the next float above, a tie goes to the even mantissa
+            const float t = (float)iou_thr;
+            uint32_t tb;
+            std::memcpy(&tb, &t, 4);
+            k3.sup.m = ((double)t + (double)std::nextafterf(t, INFINITY)) * 0.5;
+            k3.sup.tie_incl = (tb & 1u) == 0;
+        }
         k3.max_det = max_det;
         k3.out_boxes = (float4 *)out_boxes + (size_t)b0 * max_det;
         k3.out_scores = out_scores + (size_t)b0 * max_det;
@@ -460,6 +552,10 @@ extern "C" int rva_postprocess_batch(rva_ctx *ctx, const void *raw, int raw_dtyp
     RVA_HIP(ctx, hipGetLastError());
     return RVA_OK;
 }
+
+#ifdef RVA_K3_STAMPS
+extern "C" int rva_dbg_k3_stamps(unsigned long long *host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_k3_stamps), sizeof(unsigned long long) * 64 * 8); }
+#endif
 
 extern "C" int rva_post_status(rva_ctx *ctx, rva_stream_t stream_, int *flags)
 {

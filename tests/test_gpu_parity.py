@@ -127,6 +127,47 @@ def test_postprocess_busy_images_across_sort_sizes_and_nms_rounds():
     assert ops.post_status() == 0
 
 
+def test_postprocess_suppression_decisions_at_the_threshold_boundary():
+    """K3 decides `iou > thr` without dividing (an exact comparison in float64 against the point where the rounded quotient
+    leaves thr).  Pairs of boxes whose float32 IoU lands within a few ulps of the threshold, on both sides of it and on it:
+    the lower-scored box must survive exactly when the oracle's divided `iou <= thr` says so.  Identity letterbox (640x640
+    source), so the head's cx / cy / w / h are the boxes."""
+    rng = np.random.default_rng(3)
+    f32 = np.float32
+    for thr in (0.45, 0.5, 0.7, 0.3):
+        t = f32(thr)
+        r = (1.0 - thr) / (1.0 + thr)                                 # shift / width at which two equal boxes have IoU = thr
+        a = rng.integers(40, 300, 4000).astype(f32) * f32(0.5)        # widths / heights on a 0.5 grid: halves are exact
+        b = rng.integers(40, 300, 4000).astype(f32) * f32(0.5)
+        dx = (a * f32(r)).astype(f32)
+        for _ in range(3):                                            # walk dx onto the boundary in float32 steps
+            inter = (a - dx) * b
+            q = inter / np.maximum(a * b + a * b - inter, f32(1e-6))
+            dx = np.where(q > t, np.nextafter(dx, f32(1e9)), np.nextafter(dx, f32(-1e9))).astype(f32)
+        dx = np.concatenate([np.nextafter(dx, f32(-1e9)), dx, np.nextafter(dx, f32(1e9))]).astype(f32)
+        a, b = np.tile(a, 3), np.tile(b, 3)
+        inter = (a - dx) * b
+        q = inter / np.maximum(a * b + a * b - inter, f32(1e-6))
+        near = np.abs(q.astype(np.float64) - float(t)) <= 4 * np.spacing(t)
+        pick = np.concatenate([np.flatnonzero(near & (q > t))[:256], np.flatnonzero(near & (q <= t))[:256]])
+        a, b, dx, q = a[pick], b[pick], dx[pick], q[pick]
+        assert (q > t).sum() >= 64 and (q <= t).sum() >= 64
+        heads = np.zeros((len(a), 84, 128), f32)                      # [84, 128]: 128 anchors (rows < cols), two of them candidates
+        heads[:, 0, 0] = a / 2 + 100; heads[:, 1, 0] = b / 2 + 100; heads[:, 2, 0] = a; heads[:, 3, 0] = b
+        heads[:, 0, 1] = a / 2 + 100 + dx; heads[:, 1, 1] = b / 2 + 100; heads[:, 2, 1] = a; heads[:, 3, 1] = b
+        heads[:, 4, :2] = 1.0
+        heads[:, 5, 0] = 0.9; heads[:, 5, 1] = 0.8
+        n_sup = 0
+        for i0 in range(0, len(a), 64):
+            h = np.ascontiguousarray(heads[i0:i0 + 64])
+            res = ops.postprocess(torch.from_numpy(h).to(DEV), 0.25, thr, None, [N.letterbox(640, 640, 640, 640)]).to_host()
+            for k, got in enumerate(res):
+                want = orc.postprocess(h[k], 0.25, thr, None, (640, 640))
+                assert got["n"] == want["n"] and np.array_equal(got["anchor"], want["anchor"]), (thr, i0 + k)
+                n_sup += want["n"] == 1
+        assert 0 < n_sup < len(a)                                     # both outcomes occurred
+
+
 def test_postprocess_properties_at_full_size():
     """Size-independent properties on the [32,84,8400] workload: idempotence of NMS on its own
     output, descending scores, every kept pair has IoU <= thr."""
