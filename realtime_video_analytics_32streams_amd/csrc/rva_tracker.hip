@@ -230,20 +230,26 @@ __device__ __forceinline__ void k4_scan_row(const double *row, const int (&src)[
 #pragma unroll
     for (int r = 0; r < RN; ++r) v[r] = row[src[r]];            // all reads in flight before the first compare
 #pragma unroll
-    for (int r = 0; r < RN; ++r) {
+    for (int r = 0; r < RN; ++r) {        // branch-free (selects): a short-circuit `if` becomes two exec-mask branches per row here
         const int k = lane + 64 * r;
-        if (k < n && v[r] >= min_iou && v[r] > best) { best = v[r]; bi = k; }   // tracker.py:106
+        const bool take = (k < n) & (v[r] >= min_iou) & (v[r] > best);          // tracker.py:106
+        best = take ? v[r] : best;
+        bi = take ? k : bi;
     }
 }
 
+// Two waves per stream.  Wave 0 does the work; in the matrix form wave 1 is its loader: it issues the LDS-DMA of the next
+// chunk of V rows and waits for it while wave 0 consumes the current one (one workgroup barrier per chunk) -- issuing 32
+// DMA pieces per chunk cost the lone wave a quarter of its loop.  Everywhere else wave 1 leaves at once.
 template <bool F64SRC>
-__global__ void __launch_bounds__(64) k4_update(K4Args a)
+__global__ void __launch_bounds__(128) k4_update(K4Args a)
 {
-    const int s = blockIdx.x, lane = threadIdx.x;
+    const int s = blockIdx.x, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int slot = F64SRC ? a.slot[s] : (int)a.kslot[s];
     if (F64SRC ? slot == 2 : slot == -3) return;   // another launch of this tick owns the stream: leave everything alone
     if (F64SRC ? slot == 0 : slot == -1) {  // stream not updated this tick
-        if (lane == 0) { a.n_new[s] = 0; a.processed[s] = -1; a.emitted[s] = 0; }
+        if (wave == 0 && lane == 0) { a.n_new[s] = 0; a.processed[s] = -1; a.emitted[s] = 0; }
         return;
     }
     K4Gate g{true, 0, 0, 1, 0, 1, 0};
@@ -268,7 +274,7 @@ __global__ void __launch_bounds__(64) k4_update(K4Args a)
         const int CH = 32 * rowb <= K4_RING_BYTES ? 16 : (16 * rowb <= K4_RING_BYTES ? 8 : 4);   // detections per half of the ring
         const double *Vs = a.V + (size_t)s * a.dm * a.ld;
         const size_t ob = (size_t)slot * a.max_det;
-        for (int k = lane; k < cap; k += 64) l_cnt[k] = 0;
+        if (wave == 0) for (int k = lane; k < cap; k += 64) l_cnt[k] = 0;
         // filter_detections (pipeline.py:182): detections below the threshold do not exist for the tracker
         unsigned long long passw = 0ull;                            // lane i: detections 64 i .. 64 i + 63
         for (int i = 0; i * 64 < D; ++i) {
@@ -293,10 +299,17 @@ __global__ void __launch_bounds__(64) k4_update(K4Args a)
                     k4_dma16((unsigned)((size_t)d_ * a.ld * 8 + p_ * 1024 + lane * 16), Vs, dst_ + p_ * 1024);    \
             }                                                                                                     \
         } while (0)
-        if (nchunks) K4_ISSUE(0);
+        if (wave == 1) {    // the loader: chunk c + 1 travels while wave 0 works on chunk c
+            if (nchunks) K4_ISSUE(0);
+            for (int c = 0; c < nchunks; ++c) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // chunk c has landed ...
+                __syncthreads();                                    // ... and wave 0 is done with chunk c - 1: its half is free
+                if (c + 1 < nchunks) K4_ISSUE(c + 1);
+            }
+            return;
+        }
         for (int c = 0; c < nchunks; ++c) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this chunk's rows have landed (issued a chunk ago)
-            if (c + 1 < nchunks) K4_ISSUE(c + 1);                   // the other half was last read a chunk ago
+            __syncthreads();                                        // the loader has seen chunk c land
             const int dend = (c + 1) * CH < D ? (c + 1) * CH : D;
             for (int d = c * CH; d < dend; ++d) {
                 const unsigned long long pw = readlane_u64(passw, d >> 6);
@@ -335,7 +348,7 @@ __global__ void __launch_bounds__(64) k4_update(K4Args a)
                     ++n; ++created;
                 } else {        // :81-92
                     rowi = hit;
-                    if (lane == 0) l_cnt[hit] += 1;
+                    if (lane == 0) __hip_atomic_fetch_add(&l_cnt[hit], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ds_add, no round trip
                 }
                 const int rr = rowi >> 6, val = T0r + d;
                 const bool own = lane == (rowi & 63);
@@ -392,6 +405,7 @@ __global__ void __launch_bounds__(64) k4_update(K4Args a)
         }
     } else {
     // ---------------- in-loop form: table staged in LDS, float64 IoU inside the detection loop ------------------------
+    if (wave == 1) return;                             // one wave (a terminated wave does not take part in barriers)
     double *l_box = (double *)k4_smem;                 // [4][cap]  (component-major: conflict-free)
     double *l_conf = l_box + 4 * (size_t)cap;          // [cap]
     int64_t *l_id = (int64_t *)(l_conf + cap);         // [cap]
@@ -549,10 +563,10 @@ int launch_update(rva_tracker *t, K4Args &a, bool f64, hipStream_t stream)
     a.cap = t->cap; a.max_age = t->max_age; a.min_hits = t->min_hits; a.min_iou = t->min_iou;
     const size_t smem = k4_smem_bytes(t->cap, t->d_V != nullptr);
     a.V = f64 ? nullptr : t->d_V; a.dm = t->dm; a.ld = t->ld;
-    if (f64) k4_update<true><<<t->n_streams, 64, smem, stream>>>(a);
+    if (f64) k4_update<true><<<t->n_streams, 128, smem, stream>>>(a);
     else {
         if (a.V && a.boxes32) k4_iou<<<dim3(K4_IOU_BX, t->n_streams), 256, 0, stream>>>(a);
-        k4_update<false><<<t->n_streams, 64, smem, stream>>>(a);
+        k4_update<false><<<t->n_streams, 128, smem, stream>>>(a);
     }
     RVA_HIP(t->ctx, hipGetLastError());
     return RVA_OK;
