@@ -86,7 +86,7 @@ class FusedYoloV8:
         self._lane_of: List[int] = []       # per step: 0 = main stream, k > 0 = side stream k (detect-head branches)
         self._lane = 0
         import os
-        self._split_branches = os.environ.get("RVA_HEAD_SPLIT", "0") == "1"     # measured: no gain over one lane per level (tools/bench_cmp.sh)
+        self._split_branches = os.environ.get("RVA_HEAD_SPLIT", "0") == "1"     # measured: no gain over one lane per level (profiles/r02_head_lanes_ab.txt)
         self._forks: Dict[int, Tuple[int, int]] = {}   # side lane -> (parent lane, step index at which it forks off the parent)
         self._tunable = []
         self._build(net)

@@ -430,7 +430,7 @@ class PipelinedTicks:
         # caller's stream may be the null stream, whose queue another stream can share -- then the two networks would
         # serialise: 17.9 k instead of 20.3 k frames/s).  In this mode the plans run their detect branches in line: with two
         # forward passes in flight the side streams add nothing and, spread over more hardware queues, cost up to 25 %
-        # (tools/ab_queues_plan.sh: 1.53-1.55 ms per pass in line for 3-16 queues, 1.68-1.82 ms with side streams).
+        # (round-2 A/B, DESIGN.md section 4 item 11: 1.53-1.55 ms per pass in line for 3-16 queues, 1.68-1.82 ms with side streams).
         if self.net_streams == 2:
             self.sAs = [torch.cuda.Stream(device=self.det.device), torch.cuda.Stream(device=self.det.device)]
         else:
