@@ -320,7 +320,7 @@ def main():
     # HBM traffic of the K1 launch from rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see the file): a
     # committed measurement of exactly this launch shape, not something bench.py can collect while timing
     k1_traffic = None
-    pmc = ROOT / "profiles" / "r02_k1_pmc.json"
+    pmc = ROOT / "profiles" / "r03_k1_pmc.json"
     if pmc.exists() and S == 32 and (args.width, args.height) == (1920, 1080):
         k1_traffic = json.loads(pmc.read_text())["traffic_bytes_per_launch"]
     net_tflops = 2 * macs * S / (net_ms * 1e-3) / 1e12
@@ -359,7 +359,7 @@ def main():
                                "constant letterbox border was written by the first launch into the buffer)", "bound": "hbm",
                      "achieved": round(k1_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(k1_gbs / HBM_PEAK_GBS, 4), "traffic": k1_traffic,
-                     "traffic_source": "profiles/r02_k1_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" if k1_traffic else None,
+                     "traffic_source": "profiles/r03_k1_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; not collectable while timing)" if k1_traffic else None,
                      "algorithmic_bytes_per_launch": k1_frame_bytes * S, "avg_launch_us": round(float(k1_ms) * 1e3, 2),
                      "avg_launch_us_between_event_records": round(float(k1_bracket_ms) * 1e3, 2),
                      "timing": f"HIP start/stop events of the K1 dispatch itself (hipExtLaunchKernelGGL), every {K1_SAMPLE_EVERY}th timed tick "

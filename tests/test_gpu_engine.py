@@ -120,6 +120,8 @@ def test_every_conv_variant_agrees(shape):
             assert any(21 <= v <= 32 for v in ran), ran      # the large-tile LDS-DMA kernel took part
     if Cin % 32 == 0:
         assert any(v >= 40 for v in ran), ran          # the 32-channel-step LDS-DMA gather kernel took part
+        if k == 3 and stride == 1 and W <= 160:
+            assert any(52 <= v <= 60 for v in ran) and any(67 <= v <= 71 for v in ran), ran      # long-run kernels, 2 and 3 weight slots
 
 
 def _stem_weights(w1, b1):
