@@ -1404,15 +1404,9 @@ struct RunArgs {
     int H, W, Cin, Cout, CoutPad, act, n_tiles, M, m_tiles, apieces;
 };
 
-// WS = weight slots.  2: every step ends in `vmcnt(0)` + barrier -- the loads of step s+1 are issued at step s and waited for one
-// step later (stamps: 290-450 of ~2200 cycles per step in that wait).  3 (round 3): the weights of step s+2 are issued at step s
-// and the next chunk's run in the first two dy steps only, so at the top of a step everything issued TWO steps ago must have
-// landed and what the previous step issued may stay in flight: a counted `vmcnt(n)` (n = this wave's DMA instructions of the
-// previous step) instead of a drain (cdna_hip_programming.md T3+T4).
-template <int BM, int BN, int WGM, int WGN, int WS = 2>
+template <int BM, int BN, int WGM, int WGN>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BN <= 64 && BM <= 320 ? 4 : 2))) k_conv3_run(RunArgs a)
 {
-    static_assert(WS == 2 || WS == 3, "two or three weight slots");
     static_assert(WGM * WGN == 8, "eight waves");
     constexpr int TM = BM / WGM, TN = BN / WGN, FM = TM / 16, FN = TN / 16;
     constexpr int WPIECES = 3 * BN / 16;                  // weights [3 dx][BN] rows of one (chunk, dy) step
@@ -1431,7 +1425,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BN <= 
     const int wrow = 9 * a.Cin;
     const int apieces = a.apieces;                        // ceil((BM + 2W + 2) / 16)
     __half *act0 = (__half *)smem;                        // [2][apieces][16][32]
-    __half *wt0 = act0 + (size_t)2 * apieces * 512;       // [WS][WPIECES][16][32]
+    __half *wt0 = act0 + (size_t)2 * apieces * 512;       // [2][WPIECES][16][32]
     const unsigned lds_act = lds_addr(act0), lds_w = lds_addr(wt0);
 
     const int lrow = lane >> 2, lp = lane & 3;
@@ -1479,26 +1473,11 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BN <= 
 #pragma unroll
     for (int k = 0; k < NPW; ++k)
         if (wv + 8 * k < WPIECES) lds_dma16(woff[k], a.w, lds_w + (unsigned)(wv + 8 * k) * 1024u);
-    // this wave's DMA instructions per group (wave-uniform): weights of a step; the run pieces of parity 0 / 1
-    int nwp = 0, nap[2] = {0, 0};
-#pragma unroll
-    for (int k = 0; k < NPW; ++k) nwp += wv + 8 * k < WPIECES ? 1 : 0;
-#pragma unroll
-    for (int k = 0; k < MAXA; ++k) nap[k & 1] += wv + 8 * k < apieces ? 1 : 0;
-    int prev_n = 0;                                       // WS == 3: DMA instructions of the latest issue group
-    if (WS == 3 && nsteps > 1) {                          // step 1's weights: (chunk 0, dy 1)
-        const char *wb_ = (const char *)a.w + (size_t)(3 * a.Cin) * 2;
-#pragma unroll
-        for (int k = 0; k < NPW; ++k)
-            if (wv + 8 * k < WPIECES) lds_dma16(woff[k], wb_, lds_w + (unsigned)(WPIECES * 1024) + (unsigned)(wv + 8 * k) * 1024u);
-        prev_n = nwp;
-    }
     const int wlane = swz32(wn * TN + (lane & 15), lane >> 4);      // this lane's weight row of fragment 0, tap 0
 
     int cc = 0, dy = 0;
     for (int s = 0; s < nsteps; ++s) {
-        if (WS == 3) wait_vm_n(prev_n);                   // all but the previous step's loads have landed (vmcnt counts in issue order)
-        else wait_vm<0>();                                // everything this wave issued a step ago has landed ...
+        wait_vm<0>();                                     // everything this wave issued a step ago has landed ...
         __builtin_amdgcn_s_barrier();                     // ... and everybody's has; nobody still reads what the next burst overwrites
         // next step's weights, and this step's third of the NEXT chunk's run
         int ncc = cc, ndy = dy + 1;
@@ -1508,50 +1487,25 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BN <= 
         // waves w and w + 4 share a SIMD: the lower four issue their burst before the MFMAs, the upper four after the first
         // horizontal tap -- while one of the pair is stalled in the vector-memory issue, the other keeps the matrix core fed
         // (both bursts still have most of a step to land before the next top-of-step wait)
-        // WS == 3: the step after next
-        int n2cc = ncc, n2dy = ndy + 1;
-        if (n2dy == 3) { n2dy = 0; ++n2cc; }
-        n2cc = __builtin_amdgcn_readfirstlane(n2cc);
-        n2dy = __builtin_amdgcn_readfirstlane(n2dy);
-        const int wslot_next = __builtin_amdgcn_readfirstlane((s + 2) % 3);
 #define RUN_ISSUE()                                                                                              \
         do {                                                                                                     \
-            if (WS == 2) {                                                                                       \
-                if (s + 1 < nsteps) {                                                                            \
-                    const char *wb_ = (const char *)a.w + (size_t)(ndy * 3 * a.Cin + ncc * 32) * 2;              \
-                    const unsigned l_ = lds_w + (unsigned)((s + 1) & 1) * (unsigned)(WPIECES * 1024);            \
-                    _Pragma("unroll") for (int k = 0; k < NPW; ++k)                                              \
-                        if (wv + 8 * k < WPIECES) lds_dma16(woff[k], wb_, l_ + (unsigned)(wv + 8 * k) * 1024u);  \
-                }                                                                                                \
-                if (cc + 1 < cpt) {                                                                              \
-                    const char *ab_ = (const char *)a.in + (cc + 1) * 64;                                        \
-                    const unsigned l_ = lds_act + (unsigned)((cc + 1) & 1) * (unsigned)(apieces * 1024);         \
-                    _Pragma("unroll") for (int k = 0; k < MAXA; ++k)                                             \
-                        if (k % 3 == dy && wv + 8 * k < apieces) lds_dma16(aoff[k], ab_, l_ + (unsigned)(wv + 8 * k) * 1024u); \
-                }                                                                                                \
-            } else {                                                                                             \
-                prev_n = 0;                                                                                      \
-                if (s + 2 < nsteps) {                                                                            \
-                    const char *wb_ = (const char *)a.w + (size_t)(n2dy * 3 * a.Cin + n2cc * 32) * 2;            \
-                    const unsigned l_ = lds_w + (unsigned)wslot_next * (unsigned)(WPIECES * 1024);               \
-                    _Pragma("unroll") for (int k = 0; k < NPW; ++k)                                              \
-                        if (wv + 8 * k < WPIECES) lds_dma16(woff[k], wb_, l_ + (unsigned)(wv + 8 * k) * 1024u);  \
-                    prev_n += nwp;                                                                               \
-                }                                                                                                \
-                if (cc + 1 < cpt && dy < 2) {                                                                    \
-                    const char *ab_ = (const char *)a.in + (cc + 1) * 64;                                        \
-                    const unsigned l_ = lds_act + (unsigned)((cc + 1) & 1) * (unsigned)(apieces * 1024);         \
-                    _Pragma("unroll") for (int k = 0; k < MAXA; ++k)                                             \
-                        if ((k & 1) == dy && wv + 8 * k < apieces) lds_dma16(aoff[k], ab_, l_ + (unsigned)(wv + 8 * k) * 1024u); \
-                    prev_n += nap[dy];                                                                           \
-                }                                                                                                \
-                prev_n = __builtin_amdgcn_readfirstlane(prev_n);                                                 \
+            if (s + 1 < nsteps) {                                                                                \
+                const char *wb_ = (const char *)a.w + (size_t)(ndy * 3 * a.Cin + ncc * 32) * 2;                  \
+                const unsigned l_ = lds_w + (unsigned)((s + 1) & 1) * (unsigned)(WPIECES * 1024);                \
+                _Pragma("unroll") for (int k = 0; k < NPW; ++k)                                                  \
+                    if (wv + 8 * k < WPIECES) lds_dma16(woff[k], wb_, l_ + (unsigned)(wv + 8 * k) * 1024u);      \
+            }                                                                                                    \
+            if (cc + 1 < cpt) {                                                                                  \
+                const char *ab_ = (const char *)a.in + (cc + 1) * 64;                                            \
+                const unsigned l_ = lds_act + (unsigned)((cc + 1) & 1) * (unsigned)(apieces * 1024);             \
+                _Pragma("unroll") for (int k = 0; k < MAXA; ++k)                                                 \
+                    if (k % 3 == dy && wv + 8 * k < apieces) lds_dma16(aoff[k], ab_, l_ + (unsigned)(wv + 8 * k) * 1024u); \
             }                                                                                                    \
         } while (0)
         const bool early = wv < 4;
         if (early) RUN_ISSUE();
         const __half *ab = act0 + (size_t)(cc & 1) * apieces * 512;
-        const __half *wb = wt0 + (size_t)(WS == 3 ? s % 3 : (s & 1)) * WPIECES * 512;
+        const __half *wb = wt0 + (size_t)(s & 1) * WPIECES * 512;
         // Fragment addresses = one swizzled per-lane base per horizontal tap + instruction immediates (16 rows further the
         // rotation of swz32 is the same; weight rows are the lane's base + a multiple of 16 rows): the PMC pass showed 4.4 vector
         // instructions per MFMA in this kernel, and every one of them competes with the MFMAs for the SIMD's issue port.
@@ -1632,21 +1586,21 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BN <= 
     }
 }
 
-template <int BM, int BN, int WGM, int WGN, int WS = 2>
+template <int BM, int BN, int WGM, int WGN>
 hipError_t launch_run(RunArgs &a, hipStream_t s)
 {
     if (a.Cin % 32 || a.CoutPad % 4 || a.W > 160) return hipErrorInvalidValue;
     if ((size_t)a.M * a.ldi * 2 >= (1ull << 32) || (size_t)a.CoutPad * 9 * a.Cin * 2 >= (1ull << 32)) return hipErrorInvalidValue;
     a.apieces = rva_ceil_div(BM + 2 * a.W + 2, 16);
     if (a.apieces > 8 * 5) return hipErrorInvalidValue;   // MAXA pieces per wave
-    const size_t ring = (size_t)(2 * a.apieces + WS * (3 * BN / 16)) * 1024;
+    const size_t ring = (size_t)(2 * a.apieces + 2 * (3 * BN / 16)) * 1024;
     const size_t st = (size_t)BM * (BN + 8) * 2;
     const size_t smem = ring > st ? ring : st;
     if (smem > 160 * 1024) return hipErrorInvalidValue;
-    if (hipError_t e = rva_func_smem((const void *)k_conv3_run<BM, BN, WGM, WGN, WS>, 160 * 1024); e != hipSuccess) return e;
+    if (hipError_t e = rva_func_smem((const void *)k_conv3_run<BM, BN, WGM, WGN>, 160 * 1024); e != hipSuccess) return e;
     a.n_tiles = rva_ceil_div(a.Cout, BN);
     a.m_tiles = rva_ceil_div(a.M, BM);
-    k_conv3_run<BM, BN, WGM, WGN, WS><<<rva_ceil_div(a.m_tiles, 8) * 8 * a.n_tiles, 512, smem, s>>>(a);
+    k_conv3_run<BM, BN, WGM, WGN><<<rva_ceil_div(a.m_tiles, 8) * 8 * a.n_tiles, 512, smem, s>>>(a);
     return hipGetLastError();
 }
 
@@ -2687,7 +2641,7 @@ __global__ void __launch_bounds__(1024) k_stem2(Stem2Args a)
 
 }  // namespace
 
-#define RVA_CONV_VARIANTS 71
+#define RVA_CONV_VARIANTS 66
 
 extern "C" {
 #ifdef RVA_ROW_STAMPS
@@ -2767,7 +2721,7 @@ int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *wei
             if (rc == RVA_OK) return rc;
         }
     }
-    if (variant == 66) {
+    if (variant >= 66) {
         // patch kernel with two wave sets half a tile period apart (3x3 stride 1, Cin = 64, Cout <= 64)
         hipError_t ev = hipErrorInvalidValue;
         S2Args g{a.in, ldi, a.w, bias, a.out, ldo, a.res, ldr, batch, H, W, a.Ho, a.Wo, Cout, cpad, act, 0, 0, 0};
@@ -2778,7 +2732,7 @@ int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *wei
         (void)hipGetLastError();
         return rva_fail(ctx, ev == hipErrorInvalidValue ? RVA_ERR_ARG : RVA_ERR_HIP, "conv variant %d not applicable here", variant);
     }
-    if (variant == 64 || variant == 65) {
+    if (variant >= 64) {
         // LDS-DMA gather kernel with 256-channel output tiles: 43-64 MACs per staged byte against 32 of the 128 x 128 tile.  The CU's
         // vector-memory path moves 64 B/clk, its MFMAs 4096 MAC/clk: below 64 MAC/B the staging, not the matrix pipe, caps a
         // 1x1 convolution (a plain GEMM, no tap reuse).  One block per CU.
@@ -2793,7 +2747,7 @@ int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *wei
         (void)hipGetLastError();
         return rva_fail(ctx, ev == hipErrorInvalidValue ? RVA_ERR_ARG : RVA_ERR_HIP, "conv variant %d not applicable here", variant);
     }
-    if ((variant >= 52 && variant <= 60) || (variant >= 67 && variant <= 71)) {
+    if (variant >= 52 && variant <= 60) {
         // "long run" LDS-DMA kernels (3x3 stride 1, Cin % 32 == 0): a chunk's activation run staged once for all three dy
         hipError_t ev = hipErrorInvalidValue;
         if (ksize == 3 && stride == 1) {
@@ -2809,13 +2763,7 @@ int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *wei
             case 57: ev = launch_run<128, 128, 2, 4>(g, s); break;
             case 58: ev = launch_run<224, 128, 2, 4>(g, s); break;    // tile heights that fit whole rounds of the 256 CUs better
             case 59: ev = launch_run<160, 128, 2, 4>(g, s); break;
-            case 60: ev = launch_run<320, 64, 4, 2>(g, s); break;
-            // three weight slots, counted vmcnt (round 3)
-            case 67: ev = launch_run<256, 128, 4, 2, 3>(g, s); break;
-            case 68: ev = launch_run<256, 64, 4, 2, 3>(g, s); break;
-            case 69: ev = launch_run<128, 128, 2, 4, 3>(g, s); break;
-            case 70: ev = launch_run<224, 128, 2, 4, 3>(g, s); break;
-            default: ev = launch_run<128, 64, 2, 4, 3>(g, s); break;
+            default: ev = launch_run<320, 64, 4, 2>(g, s); break;
             }
         }
         if (ev == hipSuccess) return RVA_OK;

@@ -121,7 +121,7 @@ def test_every_conv_variant_agrees(shape):
     if Cin % 32 == 0:
         assert any(v >= 40 for v in ran), ran          # the 32-channel-step LDS-DMA gather kernel took part
         if k == 3 and stride == 1 and W <= 160:
-            assert any(52 <= v <= 60 for v in ran) and any(67 <= v <= 71 for v in ran), ran      # long-run kernels, 2 and 3 weight slots
+            assert any(52 <= v <= 60 for v in ran), ran    # the long-run kernels took part
 
 
 def _stem_weights(w1, b1):
