@@ -321,20 +321,24 @@ __global__ void __launch_bounds__(K3_THREADS) k3_nms(K3Args a)
 
     K3_STAMP(1);
     const int scw = SC >> 6;                                       // mask words per survivor row
-    for (int base = 0; base < K; base += SC) {
+    // Rounds grow 64, 128, 256, ... up to SC boxes: the first rounds have no kept list to thin them out, so every box of theirs
+    // reaches the quadratic phase 2 -- 64^2/2 + 128^2/2 + 256^2/2 IoUs instead of 512^2/2 -- and they fill the kept list that
+    // lets phase 1 kill most of the later, full-size rounds.
+    int rs = 64;
+    for (int base = 0; base < K; base += rs, rs = rs * 2 < SC ? rs * 2 : SC) {
         // ---- phase 1: a box against everything kept so far; two threads per box (t and t + 512) share the kept list
         // (even / odd groups of four)
         const int bt = tid & (K3_THREADS / 2 - 1), half = tid / (K3_THREADS / 2);
         const int j = base + bt;
-        const bool valid = bt < SC && j < K;
+        const bool valid = bt < rs && j < K;
         const int an = valid ? (int)(uint32_t)keys[j] : 0;
         const float4 bx = valid ? box[an] : make_float4(0.f, 0.f, 0.f, 0.f);
         bool alive = valid;
         const int nk = s_ctl[1] < a.max_det ? s_ctl[1] : a.max_det;
         const int nk_lds = nk < K3_KBL ? nk : K3_KBL;
+        const float area_b = box_area(bx);
         // four kept boxes per step, branch-free: the (broadcast) LDS reads and the four tests of a step overlap, one
         // early-exit test per step
-        const float area_b = box_area(bx);
         for (int i = 4 * half; i < nk_lds; i += 8) {
             if (!__any(alive)) break;
             float4 k4[4];

@@ -21,10 +21,15 @@
 //              stored as 0.0 (the reference skips such tracks, and a 0.0 can never win `iou > best`, best >= 0).  Same
 //              iou64(), same argument order, -ffp-contract=off: the values the serial scan would have computed, because
 //              a row's box at any point of the frame is either its old box or the box of the last detection matched to it.
-//   k4_update  one wave per stream: per row a register holds which column of V currently stands for the row (itself,
-//              or T0r + last matching detection); a detection gathers its row of V from an LDS ring (filled 4-16 rows
-//              ahead by LDS-DMA), takes the maximum with the earliest row on ties, and repoints one register.  No
-//              float64 arithmetic and no global memory access inside the loop.
+//              The block that writes a row also reduces it: A[d] = the row the reference's scan would pick if NO row had
+//              been touched by an earlier detection of the frame (maximum over columns 0..T0, earliest row on ties), and
+//              a flag saying whether ANY earlier detection's box qualifies against d (a column T0r + d' >= min_iou).
+//   k4_update  one wave per stream, 64 detections per step, one per lane.  A detection whose flag is clear and whose
+//              A row is untouched so far (or which has no A row: a new track) needs no scan: untouched rows still hold the
+//              boxes A was computed against, and no touched or new row can reach min_iou.  All such detections up to the
+//              first one that fails the test are applied at once (distinct rows, new rows numbered by a ballot prefix);
+//              the one that fails -- two detections sharing a best track, or overlapping an earlier detection -- takes the
+//              reference's scan over the live rows through a per-row column pointer, then the step resumes behind it.
 #include <climits>
 #include <cstring>
 
@@ -54,6 +59,7 @@ struct rva_tracker {
     int32_t *d_gidx = nullptr;    // [S]
     double *d_bscale = nullptr;   // [S] box scale of _rescale_detections (1.0 = no downsample)
     double *d_V = nullptr;        // [S][dm][ld] IoU matrix of the tick (k4_iou -> k4_update), null: always the in-loop form
+    int32_t *d_A = nullptr;       // [S][dm] per detection: (row picked among the untouched tracks + 1) | (an earlier detection qualifies) << 16
     int dm = 0, ld = 0;           // detections per frame the matrix holds; row stride in doubles (multiple of 128)
     // pre-detector gates decided on the device (pipeline.py:156-170, 242-262), see rva_tracker_set_gates
     int32_t *gate_cfg = nullptr;    // [S][4] adaptive enabled, max_process_every, idle_tolerance, motion minimum count
@@ -90,11 +96,10 @@ struct K4Args {
     // f64 source (host API)
     const int32_t *offs; const double *boxes64; const double *conf64; const int64_t *cls64;
     // IoU matrix path (f32 source only)
-    double *V; int dm, ld;
+    double *V; int32_t *A; int dm, ld;
 };
 
-constexpr int K4_RMAX = 16;            // matrix path: 64 * 16 rows per stream at most (capacity <= 1024)
-constexpr int K4_RING_BYTES = 96 * 1024;
+constexpr int K4_MATRIX_CAP = 1024;   // matrix path: capacities up to this many rows per stream
 
 __device__ __forceinline__ int k4_round128(int v) { return (v + 127) & ~127; }
 inline int k4_round128_host(int v) { return (v + 127) & ~127; }
@@ -140,14 +145,6 @@ __device__ __forceinline__ double iou64(const double a0, const double a1, const 
     return __ddiv_rn(inter, uni);
 }
 
-__device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int l)
-{
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
-    return ((unsigned long long)hi << 32) | lo;
-}
-__device__ __forceinline__ double readlane_f64(double v, int l) { return __longlong_as_double((long long)readlane_u64((unsigned long long)__double_as_longlong(v), l)); }
-
 extern __shared__ __attribute__((aligned(16))) unsigned char k4_smem[];
 
 // a detection of the float32 source as the tracker sees it: exact widening, then _rescale_detections (float64 multiply)
@@ -160,12 +157,17 @@ __device__ __forceinline__ void k4_det_box(const K4Args &a, size_t o, double bs,
 
 // ---- IoU matrix of the tick -------------------------------------------------------------------------------------------
 // grid = (K4_IOU_BX, streams), 256 threads.  A block takes tiles of 4 detections (rows of V) and sweeps the columns: the
-// T0 tracks the frame starts with, then the detections before the row's own.  Streams that k4_update will not run the
-// matrix form for (no frame, skipped frame, gated out, more than dm detections) return at once.
+// T0 tracks the frame starts with, then the detections before the row's own; every thread keeps the best qualifying track
+// column of its share (ascending, `>`: earliest on ties) and the block reduces them (LDS max of the value's bit pattern --
+// IoUs are non-negative doubles, so the patterns order like the values -- then min of the row among the holders of the
+// maximum).  Streams that k4_update will not run the matrix form for (no frame, skipped frame, gated out, more than dm
+// detections) return at once.
 constexpr int K4_IOU_BX = 16;
 
 __global__ void __launch_bounds__(256) k4_iou(K4Args a)
 {
+    __shared__ unsigned long long mx[4];
+    __shared__ int mi[4], bf[4];
     const int s = blockIdx.y, tid = threadIdx.x;
     const int slot = (int)a.kslot[s];
     if (slot < 0) return;
@@ -177,8 +179,10 @@ __global__ void __launch_bounds__(256) k4_iou(K4Args a)
     const size_t tb = (size_t)s * a.cap;
     double *Vs = a.V + (size_t)s * a.dm * a.ld;
     for (int d0 = blockIdx.x * 4; d0 < D; d0 += K4_IOU_BX * 4) {
-        double db[4][4];
-        int dc[4];
+        if (tid < 4) { mx[tid] = 0ull; mi[tid] = INT_MAX; bf[tid] = 0; }
+        __syncthreads();
+        double db[4][4], lb[4] = {0.0, 0.0, 0.0, 0.0};   // tracker.py:100 best_iou = 0.0
+        int dc[4], li[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int d = d0 + q < D ? d0 + q : D - 1;
@@ -192,8 +196,11 @@ __global__ void __launch_bounds__(256) k4_iou(K4Args a)
             const int tc = a.cls[tb + j];
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                if (d0 + q < D)                                  // tracker.py:103-105; a = track, b = detection
-                    Vs[(size_t)(d0 + q) * a.ld + j] = tc == dc[q] ? iou64(t01.x, t01.y, t23.x, t23.y, db[q][0], db[q][1], db[q][2], db[q][3]) : 0.0;
+                if (d0 + q < D) {                                // tracker.py:103-105; a = track, b = detection
+                    const double v = tc == dc[q] ? iou64(t01.x, t01.y, t23.x, t23.y, db[q][0], db[q][1], db[q][2], db[q][3]) : 0.0;
+                    Vs[(size_t)(d0 + q) * a.ld + j] = v;
+                    if (v >= a.min_iou && v > lb[q]) { lb[q] = v; li[q] = j; }      // :106
+                }
         }
         for (int e = tid; e < d0 + 3 && e < D; e += 256) {     // columns T0r + e: a row that detection e (re)wrote earlier in the frame
             const size_t o = (size_t)slot * a.max_det + e;
@@ -202,54 +209,33 @@ __global__ void __launch_bounds__(256) k4_iou(K4Args a)
             const int ec = a.cls32[o];                           // a row's class is the class of every detection matched to it
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                if (d0 + q < D && e < d0 + q)
-                    Vs[(size_t)(d0 + q) * a.ld + T0r + e] = ec == dc[q] ? iou64(e0, e1, e2, e3, db[q][0], db[q][1], db[q][2], db[q][3]) : 0.0;
+                if (d0 + q < D && e < d0 + q) {
+                    const double v = ec == dc[q] ? iou64(e0, e1, e2, e3, db[q][0], db[q][1], db[q][2], db[q][3]) : 0.0;
+                    Vs[(size_t)(d0 + q) * a.ld + T0r + e] = v;
+                    if (v >= a.min_iou && v > 0.0) bf[q] = 1;    // could win the scan if its row is live: k4_update decides
+                }
         }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (lb[q] > 0.0) __hip_atomic_fetch_max(&mx[q], (unsigned long long)__double_as_longlong(lb[q]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (lb[q] > 0.0 && (unsigned long long)__double_as_longlong(lb[q]) == mx[q])
+                __hip_atomic_fetch_min(&mi[q], li[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __syncthreads();
+        if (tid < 4 && d0 + tid < D) a.A[(size_t)s * a.dm + d0 + tid] = (mi[tid] == INT_MAX ? 0 : mi[tid] + 1) | (bf[tid] << 16);
     }
 }
 
-typedef __attribute__((address_space(3))) void *k4_lds_ptr;
-__device__ __forceinline__ unsigned k4_lds_addr(const void *p) { return (unsigned)(size_t)(k4_lds_ptr)p; }
-
-// one 1 KiB LDS-DMA piece: 64 lanes x 16 B from sbase + voff to LDS m0v + 16 * lane (the form rva_conv.hip documents)
-__device__ __forceinline__ void k4_dma16(unsigned voff, const void *sbase, unsigned m0v)
-{
-    const unsigned long long b = (unsigned long long)(size_t)sbase;
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
-    const unsigned long long sb = ((unsigned long long)hi << 32) | lo;
-    const unsigned m0s = __builtin_amdgcn_readfirstlane(m0v);
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sb), "s"(m0s) : "memory");
-}
-
-// maximum of a detection's row of V over the live rows: lane l looks at rows l, l + 64, ... (ascending, so `>` keeps the
-// earliest row of a lane on ties); src[r] = the column of V that stands for row l + 64 r
-template <int RN>
-__device__ __forceinline__ void k4_scan_row(const double *row, const int (&src)[K4_RMAX], int lane, int n, double min_iou, double &best, int &bi)
-{
-    double v[RN];
-#pragma unroll
-    for (int r = 0; r < RN; ++r) v[r] = row[src[r]];            // all reads in flight before the first compare
-#pragma unroll
-    for (int r = 0; r < RN; ++r) {        // branch-free (selects): a short-circuit `if` becomes two exec-mask branches per row here
-        const int k = lane + 64 * r;
-        const bool take = (k < n) & (v[r] >= min_iou) & (v[r] > best);          // tracker.py:106
-        best = take ? v[r] : best;
-        bi = take ? k : bi;
-    }
-}
-
-// Two waves per stream.  Wave 0 does the work; in the matrix form wave 1 is its loader: it issues the LDS-DMA of the next
-// chunk of V rows and waits for it while wave 0 consumes the current one (one workgroup barrier per chunk) -- issuing 32
-// DMA pieces per chunk cost the lone wave a quarter of its loop.  Everywhere else wave 1 leaves at once.
 template <bool F64SRC>
-__global__ void __launch_bounds__(128) k4_update(K4Args a)
+__global__ void __launch_bounds__(64) k4_update(K4Args a)
 {
-    const int s = blockIdx.x, lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int s = blockIdx.x, lane = threadIdx.x;
     const int slot = F64SRC ? a.slot[s] : (int)a.kslot[s];
     if (F64SRC ? slot == 2 : slot == -3) return;   // another launch of this tick owns the stream: leave everything alone
     if (F64SRC ? slot == 0 : slot == -1) {  // stream not updated this tick
-        if (wave == 0 && lane == 0) { a.n_new[s] = 0; a.processed[s] = -1; a.emitted[s] = 0; }
+        if (lane == 0) { a.n_new[s] = 0; a.processed[s] = -1; a.emitted[s] = 0; }
         return;
     }
     K4Gate g{true, 0, 0, 1, 0, 1, 0};
@@ -265,111 +251,88 @@ __global__ void __launch_bounds__(128) k4_update(K4Args a)
     bool overflow = false;
 
     if (!F64SRC && a.V && D <= a.dm) {
-        // ---------------- matrix form: the IoUs are in V (k4_iou), the loop only picks and repoints ----------------------
+        // ---------------- matrix form: the IoUs are in V, the picks of untouched rows in A (k4_iou) ------------------------
         const int T0 = n, T0r = k4_round128(T0);
-        int32_t *l_cnt = (int32_t *)k4_smem;                        // [cap] matches of the frame per row (a new row starts at 1)
-        unsigned char *ring = k4_smem + (((size_t)cap * 4 + 1023) & ~(size_t)1023);
-        const unsigned ring_lds = k4_lds_addr(ring);
-        const int rowb = ((T0r + D) * 8 + 1023) & ~1023;            // bytes of a ring row: whole 1 KiB pieces
-        const int CH = 32 * rowb <= K4_RING_BYTES ? 16 : (16 * rowb <= K4_RING_BYTES ? 8 : 4);   // detections per half of the ring
+        int32_t *l_cnt = (int32_t *)k4_smem;        // [cap] matches of the frame per row (a new row starts at 1)
+        int32_t *l_src = l_cnt + cap;               // [cap] the column of V that stands for the row now: itself, or T0r + last matching detection
+        int32_t *l_first = l_src + cap;             // [cap] earliest detection of the frame that picked / touched the row
         const double *Vs = a.V + (size_t)s * a.dm * a.ld;
+        const int32_t *As = a.A + (size_t)s * a.dm;
         const size_t ob = (size_t)slot * a.max_det;
-        if (wave == 0) for (int k = lane; k < cap; k += 64) l_cnt[k] = 0;
-        // filter_detections (pipeline.py:182): detections below the threshold do not exist for the tracker
-        unsigned long long passw = 0ull;                            // lane i: detections 64 i .. 64 i + 63
-        for (int i = 0; i * 64 < D; ++i) {
-            const int d = i * 64 + lane;
-            const unsigned long long m = __ballot(d < D && (double)a.scores32[ob + (d < D ? d : 0)] >= a.filter_thr);
-            if (lane == i) passw = m;
-            n_emit += __popcll(m);
-        }
-        int src[K4_RMAX];
-#pragma unroll
-        for (int r = 0; r < K4_RMAX; ++r) src[r] = lane + 64 * r < T0 ? lane + 64 * r : 0;
-
-        const int nchunks = (D + CH - 1) / CH;
-        // rows [c CH, (c+1) CH) of V -> ring half c & 1: row d needs its first T0r + d columns
-#define K4_ISSUE(c_)                                                                                              \
-        do {                                                                                                      \
-            const int c__ = (c_);                                                                                 \
-            for (int d_ = c__ * CH; d_ < (c__ + 1) * CH && d_ < D; ++d_) {                                        \
-                const int pieces_ = ((T0r + d_) * 8 + 1023) >> 10;                                                \
-                const unsigned dst_ = ring_lds + (unsigned)(((c__ & 1) * CH + (d_ - c__ * CH)) * rowb);           \
-                for (int p_ = 0; p_ < pieces_; ++p_)                                                              \
-                    k4_dma16((unsigned)((size_t)d_ * a.ld * 8 + p_ * 1024 + lane * 16), Vs, dst_ + p_ * 1024);    \
-            }                                                                                                     \
-        } while (0)
-        if (wave == 1) {    // the loader: chunk c + 1 travels while wave 0 works on chunk c
-            if (nchunks) K4_ISSUE(0);
-            for (int c = 0; c < nchunks; ++c) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // chunk c has landed ...
-                __syncthreads();                                    // ... and wave 0 is done with chunk c - 1: its half is free
-                if (c + 1 < nchunks) K4_ISSUE(c + 1);
-            }
-            return;
-        }
-        for (int c = 0; c < nchunks; ++c) {
-            __syncthreads();                                        // the loader has seen chunk c land
-            const int dend = (c + 1) * CH < D ? (c + 1) * CH : D;
-            for (int d = c * CH; d < dend; ++d) {
-                const unsigned long long pw = readlane_u64(passw, d >> 6);
-                if (!((pw >> (d & 63)) & 1ull)) continue;
-                const double *row = reinterpret_cast<const double *>(ring + (size_t)((c & 1) * CH + (d - c * CH)) * rowb);
-                double best = 0.0;  // tracker.py:100
+        int nx_info = 0;
+        float nx_sc = 0.f;
+        if (lane < D) { nx_info = As[lane]; nx_sc = a.scores32[ob + lane]; }
+        for (int k = lane; k < cap; k += 64) { l_cnt[k] = 0; l_src[k] = k; l_first[k] = INT_MAX; }
+        __syncthreads();
+        const unsigned long long below = (1ull << lane) - 1ull;
+        for (int db = 0; db < D; db += 64) {
+            const int d = db + lane;
+            const int info = nx_info;
+            const float sc = nx_sc;
+            if (d + 64 < D) { nx_info = As[d + 64]; nx_sc = a.scores32[ob + d + 64]; }
+            // filter_detections (pipeline.py:182): detections below the threshold do not exist for the tracker
+            const bool pass = d < D && (double)sc >= a.filter_thr;
+            n_emit += __popcll(__ballot(pass));
+            const int arow = (info & 0xffff) - 1;
+            const bool later = (info >> 16) & 1;
+            if (pass && arow >= 0) __hip_atomic_fetch_min(&l_first[arow], d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __syncthreads();
+            int start = 0;
+            for (;;) {
+                const bool open = pass && lane >= start;
+                const bool scan = open && (later || (arow >= 0 && l_first[arow] != d));
+                const unsigned long long sm = __ballot(scan);
+                const int c = sm ? __builtin_ctzll(sm) : 64;
+                // lanes [start, c): distinct untouched rows or new tracks, none of them visible to another -- all at once
+                const bool act = open && lane < c;
+                const bool fresh = act && arow < 0;             // tracker.py:69-80 new track, appended in detection order
+                const unsigned long long nm = __ballot(fresh);
+                const int room = cap - n, rank = __popcll(nm & below), nn = __popcll(nm);
+                if (fresh && rank < room) { l_cnt[n + rank] = 1; l_src[n + rank] = T0r + d; }
+                if (act && arow >= 0) { l_cnt[arow] += 1; l_src[arow] = T0r + d; }   // :81-92
+                if (nn > room) overflow = true;
+                n += nn < room ? nn : room;
+                created += nn < room ? nn : room;
+                if (c == 64) break;
+                __syncthreads();
+                // detection db + c: the reference's scan over the live rows (tracker.py:100-109), each at its current column
+                const int dc = db + c;
+                const double *row = Vs + (size_t)dc * a.ld;
+                double best = 0.0;
                 int bi = INT_MAX;
-                const int rn = (n + 63) >> 6;
-                if (rn <= 2) k4_scan_row<2>(row, src, lane, n, a.min_iou, best, bi);
-                else if (rn <= 4) k4_scan_row<4>(row, src, lane, n, a.min_iou, best, bi);
-                else if (rn <= 8) k4_scan_row<8>(row, src, lane, n, a.min_iou, best, bi);
-                else k4_scan_row<K4_RMAX>(row, src, lane, n, a.min_iou, best, bi);
-                unsigned long long m = __ballot(bi != INT_MAX);
-                int hit = -1;
-                if (m) {
-                    // almost always one lane holds a candidate: its row is the answer.  Otherwise walk the candidates.
-                    int l = __builtin_ctzll(m);
-                    hit = __builtin_amdgcn_readlane(bi, l);
-                    m &= m - 1ull;
-                    if (m) {
-                        double bb = readlane_f64(best, l);
-                        while (m) {
-                            l = __builtin_ctzll(m);
-                            m &= m - 1ull;
-                            const double v = readlane_f64(best, l);
-                            const int k = __builtin_amdgcn_readlane(bi, l);
-                            if (v > bb || (v == bb && k < hit)) { bb = v; hit = k; }
-                        }
+                for (int k = lane; k < n; k += 64) {
+                    const double v = row[l_src[k]];
+                    if (v >= a.min_iou && v > best) { best = v; bi = k; }     // rows ascend within a lane
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const double vb = __shfl_xor(best, off);
+                    const int vi = __shfl_xor(bi, off);
+                    if (vb > best || (vb == best && vi < bi)) { best = vb; bi = vi; }
+                }
+                if (bi == INT_MAX) {
+                    if (n >= cap) overflow = true;
+                    else {
+                        if (lane == 0) { l_cnt[n] = 1; l_src[n] = T0r + dc; }
+                        ++n; ++created;
                     }
+                } else if (lane == 0) {
+                    l_cnt[bi] += 1; l_src[bi] = T0r + dc;
+                    if (dc < l_first[bi]) l_first[bi] = dc;     // a later detection that picked this row must scan too
                 }
-                int rowi;
-                if (hit < 0) {  // tracker.py:69-80 new track, appended immediately
-                    if (n >= cap) { overflow = true; continue; }
-                    rowi = n;
-                    if (lane == 0) l_cnt[n] = 1;
-                    ++n; ++created;
-                } else {        // :81-92
-                    rowi = hit;
-                    if (lane == 0) __hip_atomic_fetch_add(&l_cnt[hit], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ds_add, no round trip
-                }
-                const int rr = rowi >> 6, val = T0r + d;
-                const bool own = lane == (rowi & 63);
-                switch (rr) {   // wave-uniform: one predicated move
-#define K4_SET(R) case R: if (own) src[R] = val; break;
-                    K4_SET(0) K4_SET(1) K4_SET(2) K4_SET(3) K4_SET(4) K4_SET(5) K4_SET(6) K4_SET(7)
-                    K4_SET(8) K4_SET(9) K4_SET(10) K4_SET(11) K4_SET(12) K4_SET(13) K4_SET(14) K4_SET(15)
-#undef K4_SET
-                }
+                __syncthreads();
+                start = c + 1;
             }
+            __syncthreads();
         }
-#undef K4_ISSUE
         // every row: its final values (old ones, or those of the last detection matched to it), prune, stable compaction in
         // place (a group of 64 rows is read whole before any of its rows is written, and only rows <= the group are written)
         const double bs = a.bscale[s];
-#pragma unroll
-        for (int r = 0; r < K4_RMAX; ++r) {
-            if (r * 64 >= n) break;
-            const int k = lane + 64 * r;
+        for (int k0 = 0; k0 < n; k0 += 64) {
+            const int k = k0 + lane;
             const bool valid = k < n, old = valid && k < T0;
-            const bool touched = valid && (k >= T0 || src[r] >= T0r);
+            const int col = valid ? l_src[k] : 0;
+            const bool touched = valid && col >= T0r;
             double b0 = 0, b1 = 0, b2 = 0, b3 = 0, cf = 0;
             long long id = 0;
             int cl = 0, ag = 0, hi = 0, match = 0;
@@ -383,7 +346,7 @@ __global__ void __launch_bounds__(128) k4_update(K4Args a)
             }
             bool keep = false;
             if (touched) {
-                const int dd = src[r] - T0r;
+                const int dd = col - T0r;
                 k4_det_box(a, ob + dd, bs, b0, b1, b2, b3);
                 cf = (double)a.scores32[ob + dd];
                 if (!old) { id = -(long long)(k - T0 + 1); cl = a.cls32[ob + dd]; }
@@ -395,7 +358,7 @@ __global__ void __launch_bounds__(128) k4_update(K4Args a)
             }
             const unsigned long long m = __ballot(keep);
             if (keep) {
-                const size_t o = tb + base + __popcll(m & ((1ull << lane) - 1ull));
+                const size_t o = tb + base + __popcll(m & below);
                 reinterpret_cast<double2 *>(a.box)[2 * o] = make_double2(b0, b1);
                 reinterpret_cast<double2 *>(a.box)[2 * o + 1] = make_double2(b2, b3);
                 a.conf[o] = cf; a.id[o] = id; a.cls[o] = cl; a.age[o] = ag; a.hits[o] = hi;
@@ -405,7 +368,6 @@ __global__ void __launch_bounds__(128) k4_update(K4Args a)
         }
     } else {
     // ---------------- in-loop form: table staged in LDS, float64 IoU inside the detection loop ------------------------
-    if (wave == 1) return;                             // one wave (a terminated wave does not take part in barriers)
     double *l_box = (double *)k4_smem;                 // [4][cap]  (component-major: conflict-free)
     double *l_conf = l_box + 4 * (size_t)cap;          // [cap]
     int64_t *l_id = (int64_t *)(l_conf + cap);         // [cap]
@@ -547,13 +509,8 @@ __global__ void __launch_bounds__(64) k4_assign_ids(int64_t *id, const int32_t *
     }
 }
 
-// dynamic LDS of k4_update: the staged table of the in-loop form, or match counters + the V ring of the matrix form
-size_t k4_smem_bytes(int cap, bool matrix)
-{
-    const size_t legacy = (size_t)cap * (4 * 8 + 8 + 8 + 4 * 4) + 64;
-    const size_t mx = matrix ? (((size_t)cap * 4 + 1023) & ~(size_t)1023) + K4_RING_BYTES : 0;
-    return legacy > mx ? legacy : mx;
-}
+// dynamic LDS of k4_update: the staged table of the in-loop form (the matrix form's three int32 arrays fit inside it)
+size_t k4_smem_bytes(int cap) { return (size_t)cap * (4 * 8 + 8 + 8 + 4 * 4) + 64; }
 
 int launch_update(rva_tracker *t, K4Args &a, bool f64, hipStream_t stream)
 {
@@ -561,12 +518,12 @@ int launch_update(rva_tracker *t, K4Args &a, bool f64, hipStream_t stream)
     a.n_tracks = t->n_tracks; a.n_new = t->n_new; a.flags = t->flags;
     a.emitted = t->emitted; a.processed = t->processed;
     a.cap = t->cap; a.max_age = t->max_age; a.min_hits = t->min_hits; a.min_iou = t->min_iou;
-    const size_t smem = k4_smem_bytes(t->cap, t->d_V != nullptr);
-    a.V = f64 ? nullptr : t->d_V; a.dm = t->dm; a.ld = t->ld;
-    if (f64) k4_update<true><<<t->n_streams, 128, smem, stream>>>(a);
+    const size_t smem = k4_smem_bytes(t->cap);
+    a.V = f64 ? nullptr : t->d_V; a.A = t->d_A; a.dm = t->dm; a.ld = t->ld;
+    if (f64) k4_update<true><<<t->n_streams, 64, smem, stream>>>(a);
     else {
         if (a.V && a.boxes32) k4_iou<<<dim3(K4_IOU_BX, t->n_streams), 256, 0, stream>>>(a);
-        k4_update<false><<<t->n_streams, 128, smem, stream>>>(a);
+        k4_update<false><<<t->n_streams, 64, smem, stream>>>(a);
     }
     RVA_HIP(t->ctx, hipGetLastError());
     return RVA_OK;
@@ -584,14 +541,14 @@ int rva_tracker_create(rva_ctx *ctx, int n_streams, int capacity, int max_age, d
     // IoU matrix of a tick (k4_iou -> k4_update): up to dm detections per frame against cap tracks + dm detections, kept
     // within 512 MiB for all streams; busier frames (and capacities beyond 1024 rows) use the in-loop form
     int dm = 0, ld = 0;
-    if (capacity <= 64 * K4_RMAX) {
+    if (capacity <= K4_MATRIX_CAP) {
         const int cap_r = k4_round128_host(capacity);
         dm = cap_r < 512 ? cap_r : 512;
         while (dm > 128 && (size_t)n_streams * dm * (cap_r + dm) * 8 > ((size_t)512 << 20)) dm -= 128;
         if ((size_t)n_streams * dm * (cap_r + dm) * 8 > ((size_t)512 << 20)) dm = 0;
         ld = cap_r + dm;
     }
-    const size_t smem = k4_smem_bytes(capacity, dm > 0);
+    const size_t smem = k4_smem_bytes(capacity);
     if (smem > 160 * 1024) return rva_fail(ctx, RVA_ERR_CAPACITY, "tracker capacity %d needs %zu B of LDS (max 160 KiB)", capacity, smem);
     RVA_HIP(ctx, hipSetDevice(ctx->device));
     RVA_HIP(ctx, rva_func_smem((const void *)k4_update<true>, smem));
@@ -623,6 +580,7 @@ int rva_tracker_create(rva_ctx *ctx, int n_streams, int capacity, int max_age, d
     }
     if (dm > 0) {
         RVA_HIP(ctx, hipMalloc(&t->d_V, (size_t)n_streams * dm * ld * sizeof(double)));
+        RVA_HIP(ctx, hipMalloc(&t->d_A, (size_t)n_streams * dm * sizeof(int32_t)));
         t->dm = dm; t->ld = ld;
     }
     RVA_HIP(ctx, hipMalloc(&t->gate_cfg, n_streams * 16));
@@ -657,7 +615,7 @@ void rva_tracker_destroy(rva_tracker *t)
     (void)hipSetDevice(t->ctx->device);
     (void)hipDeviceSynchronize();
     void *dev[] = {t->id, t->box, t->conf, t->cls, t->age, t->hits, t->last_det, t->n_tracks, t->n_new, t->next_id, t->id_ticket, t->flags,
-                   t->d_slot, t->d_offs, t->d_gidx, t->d_bscale, t->gate_cfg, t->gate_state, t->emitted, t->processed, t->d_V};
+                   t->d_slot, t->d_offs, t->d_gidx, t->d_bscale, t->gate_cfg, t->gate_state, t->emitted, t->processed, t->d_V, t->d_A};
     for (void *p : dev) (void)hipFree(p);
     void *host[] = {t->h_slot, t->h_offs, t->h_read[0], t->h_read[1]};
     for (int i = 0; i < 2; ++i) if (t->snap_done[i]) (void)hipEventDestroy(t->snap_done[i]);

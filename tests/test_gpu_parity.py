@@ -311,7 +311,8 @@ def test_tracker_fused_f32_path_with_filter_and_skips():
     dict(S=4, T=30, n_obj=300, cap=1024, max_det=512, trk=(30, 0.5, 1), thr=0.3, scale=2.0),     # _rescale_detections inside
     dict(S=3, T=12, n_obj=580, cap=1024, max_det=1024, trk=(1, 0.5, 1), thr=0.3, scale=1.0),     # frames beyond the matrix's 512 detections
     dict(S=5, T=40, n_obj=40, cap=160, max_det=128, trk=(3, 0.4, 1), thr=0.5, scale=1.0),        # capacity that is no multiple of the 128-column pad
-], ids=["32x256x50", "rescaled", "beyond-matrix", "small-capacity"])
+    dict(S=4, T=25, n_obj=220, cap=1024, max_det=512, trk=(3, 0.02, 1), thr=0.3, scale=1.0),     # nearly every detection overlaps an earlier one: all scans
+], ids=["32x256x50", "rescaled", "beyond-matrix", "small-capacity", "all-scans"])
 def test_tracker_busy_frames_matrix_form_equals_reference_scan(cfg):
     """K4 under load: k4_iou fills the float64 IoU matrix of the tick on all CUs, k4_update only picks maxima -- the tables
     after EVERY tick must equal the oracle's sequential scan (ids, hits, ages, float64 boxes), in dense scenes where a
@@ -361,6 +362,39 @@ def test_tracker_busy_frames_matrix_form_equals_reference_scan(cfg):
     assert trk.state() == (ref.next_id, 0)
     assert seen_multi >= min(cfg["n_obj"] * 0.8, md * 0.8)
     trk.close()
+
+
+def test_tracker_full_table_drops_the_same_detections_in_both_forms():
+    """The table has a fixed capacity (ours, not the reference's: the flag says detections were dropped).  When it fills
+    up, the form that applies 64 detections per step must drop exactly the detections the in-loop form (float64 host
+    source, one detection at a time) drops: new tracks once the table is full, matches never."""
+    S, T, md, cap = 3, 25, 256, 120
+    script = synth.make_tracker_script(411, S, T, n_obj=150)
+    step = ops.DeviceTracker(S, 8, 0.3, 1, capacity=cap)
+    loop = ops.DeviceTracker(S, 8, 0.3, 1, capacity=cap)
+    post = ops.PostBuffers.allocate(S, md, DEV)
+    flagged = False
+    for t in range(T):
+        boxes, scores = np.zeros((S, md, 4), np.float32), np.zeros((S, md), np.float32)
+        cls, counts = np.zeros((S, md), np.int32), np.zeros(S, np.int32)
+        host = {}
+        for s in range(S):
+            fd = script[t][s]
+            d = min(len(fd.conf), md)
+            boxes[s, :d] = fd.boxes[:d]; scores[s, :d] = fd.conf[:d]; cls[s, :d] = fd.cls[:d]; counts[s] = d
+            host[s] = (boxes[s, :d].astype(np.float64), scores[s, :d].astype(np.float64), cls[s, :d].astype(np.int64))
+        post.boxes.copy_(torch.from_numpy(boxes)); post.scores.copy_(torch.from_numpy(scores))
+        post.cls.copy_(torch.from_numpy(cls)); post.counts.copy_(torch.from_numpy(counts))
+        step.update_from_post(list(range(S)), post, 0.0)
+        loop.update_from_host(host)
+        step.assign_ids(); loop.assign_ids()
+        a, b = step.read_all(), loop.read_all()
+        for s in range(S):
+            assert _gpu_table(a[s]) == _gpu_table(b[s]), (t, s)
+        assert step.state() == loop.state()
+        flagged = flagged or step.state()[1] != 0
+    assert flagged, "the scenario never filled the table"
+    step.close(); loop.close()
 
 
 def test_tracker_sharded_ids_match_single_process():
