@@ -124,20 +124,46 @@ __device__ __forceinline__ float iou32(const float4 a, const float4 b)
 // included when a tie rounds to thr (thr's mantissa even), excluded otherwise.  m has 25 significant bits and u 24: the
 // double product m * u is exact, and so is the comparison.  NaN operands make every comparison false -> suppressed, as a NaN
 // quotient does in the reference's `iou <= thr` (detector.py:373).  Same float32 operations as iou32() up to u.
-struct SupTest { double m; int tie_incl; };
+struct SupTest { double m; int tie_incl; float thr, thr_up; };
 
-__device__ __forceinline__ bool suppresses(const float4 a, const float area_a, const float4 b, const float area_b, const SupTest t)
+// v_max_f32 / v_min_f32 as fmaxf / fminf compute them for quiet NaNs (the other operand); written as instructions because
+// the compiler puts a canonicalising v_max_f32 x, x in front of every fmaxf / fminf operand that comes from memory
+__device__ __forceinline__ float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+// numerator and denominator of iou32(a, b), the same float32 operations
+__device__ __forceinline__ void iou_terms(const float4 a, const float area_a, const float4 b, const float area_b, float &inter, float &uni)
 {
-    const float x1 = fmaxf(a.x, b.x), y1 = fmaxf(a.y, b.y);
-    const float x2 = fminf(a.z, b.z), y2 = fminf(a.w, b.w);
+    const float x1 = vmax(a.x, b.x), y1 = vmax(a.y, b.y);
+    const float x2 = vmin(a.z, b.z), y2 = vmin(a.w, b.w);
     float w = x2 - x1, h = y2 - y1;
     w = w > 0.0f ? w : 0.0f;
     h = h > 0.0f ? h : 0.0f;
-    const float inter = w * h;
-    float uni = area_a + area_b - inter;
-    uni = fmaxf(uni, 1e-6f);
+    inter = w * h;
+    uni = area_a + area_b - inter;
+    uni = vmax(uni, 1e-6f);
+}
+
+__device__ __forceinline__ bool suppresses(const float4 a, const float area_a, const float4 b, const float area_b, const SupTest t)
+{
+    float inter, uni;
+    iou_terms(a, area_a, b, area_b, inter, uni);
     const double di = (double)inter, rhs = t.m * (double)uni;
     return !(t.tie_incl ? di <= rhs : di < rhs);
+}
+
+// The same decision from two float32 FMAs wherever they settle it.  fma(-c, u, inter) is the correctly rounded inter - c u, so
+// its sign is the sign of inter / u - c: not above thr -> the rounded quotient is <= thr, kept; at or above the next float
+// after thr -> the rounded quotient is above thr, suppressed.  Strictly between the two (or NaN) -> `unsure`, and the caller
+// asks suppresses().  Returns "suppressed for certain".
+__device__ __forceinline__ bool suppresses_fast(const float4 a, const float area_a, const float4 b, const float area_b, const SupTest t, bool &unsure)
+{
+    float inter, uni;
+    iou_terms(a, area_a, b, area_b, inter, uni);
+    const float lo = __builtin_fmaf(-t.thr, uni, inter), hi = __builtin_fmaf(-t.thr_up, uni, inter);
+    const bool yes = hi >= 0.0f;
+    unsure |= !(lo <= 0.0f) & !yes;
+    return yes;
 }
 __device__ __forceinline__ float box_area(const float4 b) { return (b.z - b.x) * (b.w - b.y); }
 
@@ -147,6 +173,7 @@ struct K3Args {
     const int32_t *sp_cls;
     const uint32_t *bits;
     int nwords, A, kcap;  // kcap: power of two, LDS key capacity
+    int kbl;              // kept boxes held in LDS (1024, or 512 when the keys take 128 KB)
     int sc;               // super-chunk: boxes per NMS round (512, or 256 when the keys take 128 KB of LDS)
     float iou_thr;
     SupTest sup;          // the same decision as `!(iou <= iou_thr)`, division-free (see suppresses())
@@ -167,7 +194,7 @@ __device__ unsigned long long g_k3_stamps[64][8];
 
 constexpr int K3_THREADS = 1024;   // 16 waves: four per SIMD hide the LDS / ALU latencies of the IoU loops (two did not)
 constexpr int K3_WAVES = K3_THREADS / 64;
-constexpr int K3_KBL = 1024;       // kept boxes held in LDS for phase 1 (further ones are read back from out_boxes)
+constexpr int K3_KBL = 1024;       // kept boxes held in LDS for phase 1 at most (K3Args::kbl; further ones are read back from out_boxes)
 
 extern __shared__ __attribute__((aligned(16))) unsigned char k3_smem[];
 
@@ -239,16 +266,31 @@ __device__ __forceinline__ void k3_sort(unsigned long long *keys, int tid)
     __syncthreads();
 }
 
+// output row `pos` of image b: kept box, its score / class / anchor, its index among the thresholded candidates in anchor order
+__device__ __forceinline__ void k3_emit(const K3Args &a, int b, int pos, const float4 kbx, int kan, const float *score, const uint32_t *bw, const int *wprefix)
+{
+    const long o = (long)b * a.max_det + pos;
+    a.out_boxes[o] = kbx;
+    a.out_scores[o] = score[kan];
+    a.out_cls[o] = a.sp_cls[(long)b * a.A + kan];
+    if (a.out_anchor) a.out_anchor[o] = kan;
+    if (a.out_cand) {
+        const int w = kan >> 5;
+        a.out_cand[o] = wprefix[w] + __popc(bw[w] & ((1u << (kan & 31)) - 1u));
+    }
+}
+
 __global__ void __launch_bounds__(K3_THREADS) k3_nms(K3Args a)
 {
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int SC = a.sc;
+    const int SC = a.sc, KBL = a.kbl;
     // LDS carve (all offsets multiples of 16)
     unsigned long long *keys = (unsigned long long *)k3_smem;                 // [kcap]
     size_t off = (size_t)a.kcap * 8;
-    float4 *kb = (float4 *)(k3_smem + off); off += (size_t)K3_KBL * 16;      // kept boxes so far
+    float4 *kb = (float4 *)(k3_smem + off); off += (size_t)(KBL + 8) * 16;   // kept boxes so far; the rest stays all-zero (such a box suppresses nothing a kept box would not)
     float4 *sv_box = (float4 *)(k3_smem + off); off += (size_t)SC * 16;     // survivors of phase 1, in order
     int *sv_j = (int *)(k3_smem + off); off += (size_t)SC * 4;              // their position in the sorted list
+    int *kj = (int *)(k3_smem + off); off += (size_t)KBL * 4;            // kept boxes so far: position in the sorted list
     unsigned long long *smask = (unsigned long long *)(k3_smem + off); off += (size_t)SC * (SC / 64) * 8;   // [SC][SC/64]
     int *wprefix = (int *)(k3_smem + off); off += (((size_t)a.nwords * 4 + 15) & ~(size_t)15);             // [nwords]
     int *wave_tot = (int *)(k3_smem + off); off += 64;                       // [16]
@@ -261,6 +303,7 @@ __global__ void __launch_bounds__(K3_THREADS) k3_nms(K3Args a)
     // ---- candidates = set bits of the pass bitmap: exclusive prefix of the word popcounts (512 words per round)
     const uint32_t *bw = a.bits + (long)b * a.nwords;
     if (tid == 0) { s_ctl[1] = 0; s_ctl[2] = 0; }
+    for (int i = tid; i < KBL + 8; i += K3_THREADS) kb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
     for (int w0 = 0; w0 < a.nwords; w0 += K3_THREADS) {
         const int w = w0 + tid;
@@ -335,22 +378,26 @@ __global__ void __launch_bounds__(K3_THREADS) k3_nms(K3Args a)
         const float4 bx = valid ? box[an] : make_float4(0.f, 0.f, 0.f, 0.f);
         bool alive = valid;
         const int nk = s_ctl[1] < a.max_det ? s_ctl[1] : a.max_det;
-        const int nk_lds = nk < K3_KBL ? nk : K3_KBL;
+        const int nk_lds = nk < KBL ? nk : KBL;
         const float area_b = box_area(bx);
         // four kept boxes per step, branch-free: the (broadcast) LDS reads and the four tests of a step overlap, one
-        // early-exit test per step
+        // early-exit test per step; reads past the list find all-zero boxes
         for (int i = 4 * half; i < nk_lds; i += 8) {
             if (!__any(alive)) break;
             float4 k4[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) k4[u] = kb[i + u < nk_lds ? i + u : i];        // a repeated box changes nothing
-            bool hit = false;
+            for (int u = 0; u < 4; ++u) k4[u] = kb[i + u];
+            bool hit = false, unsure = false;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) hit |= suppresses(k4[u], box_area(k4[u]), bx, area_b, a.sup);     // detector.py:373
+            for (int u = 0; u < 4; ++u) hit |= suppresses_fast(k4[u], box_area(k4[u]), bx, area_b, a.sup, unsure);     // detector.py:373
+            if (__any(unsure)) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) hit |= suppresses(k4[u], box_area(k4[u]), bx, area_b, a.sup);
+            }
             alive = alive && !hit;
         }
         const float4 *kept_glb = a.out_boxes + (long)b * a.max_det;
-        for (int i = K3_KBL + half; i < nk; i += 2) {             // more than 1024 boxes kept in one image: the rest from HBM
+        for (int i = KBL + half; i < nk; i += 2) {             // more than 1024 boxes kept in one image: the rest from HBM
             if (!__any(alive)) break;
             const float4 kg = kept_glb[i];
             alive = alive && !suppresses(kg, box_area(kg), bx, area_b, a.sup);
@@ -392,7 +439,10 @@ __global__ void __launch_bounds__(K3_THREADS) k3_nms(K3Args a)
                 for (int u = 0; u < 4; ++u) {
                     const int r = r0 + u * K3_WAVES;
                     if (r < rend) {                                // wave-uniform
-                        const bool sup = col < ns && col > r && suppresses(rb[u], box_area(rb[u]), cb, area_c, a.sup);
+                        bool unsure = false;
+                        bool sup = suppresses_fast(rb[u], box_area(rb[u]), cb, area_c, a.sup, unsure);
+                        if (__any(unsure)) sup = suppresses(rb[u], box_area(rb[u]), cb, area_c, a.sup);
+                        sup = sup && col < ns && col > r;
                         const unsigned long long w = __ballot(sup);
                         if (lane == 0) smask[(size_t)r * scw + ct] = w;
                     }
@@ -431,21 +481,9 @@ __global__ void __launch_bounds__(K3_THREADS) k3_nms(K3Args a)
                 if ((kept >> lane) & 1ull) {
                     const int pos = out0 + __popcll(kept & ((1ull << lane) - 1ull));
                     const float4 kbx = sv_box[r];
-                    if (pos < K3_KBL) kb[pos] = kbx;
-                    if (pos < a.max_det) {
-                        const int kan = (int)(uint32_t)keys[sv_j[r]];
-                        const long o = (long)b * a.max_det + pos;
-                        a.out_boxes[o] = kbx;
-                        a.out_scores[o] = score[kan];
-                        a.out_cls[o] = a.sp_cls[(long)b * a.A + kan];
-                        if (a.out_anchor) a.out_anchor[o] = kan;
-                        if (a.out_cand) {                          // index among the thresholded candidates in anchor order
-                            const int w = kan >> 5;
-                            a.out_cand[o] = wprefix[w] + __popc(bw[w] & ((1u << (kan & 31)) - 1u));
-                        }
-                    } else {
-                        atomicOr(a.flags, 1);
-                    }
+                    if (pos < KBL) { kb[pos] = kbx; kj[pos] = sv_j[r]; }      // its output row is written after the last round
+                    else if (pos < a.max_det) k3_emit(a, b, pos, kbx, (int)(uint32_t)keys[sv_j[r]], score, bw, wprefix);
+                    if (pos >= a.max_det) atomicOr(a.flags, 1);
                 }
                 out0 += __popcll(kept);
             }
@@ -453,6 +491,13 @@ __global__ void __launch_bounds__(K3_THREADS) k3_nms(K3Args a)
         }
         __syncthreads();
         K3_STAMP(5);
+    }
+    // the output rows of the kept boxes (the walk only noted which candidates they are: the score / class / bitmap reads of a
+    // row would otherwise sit in the one-wave loop, a memory round trip per 64 survivors)
+    {
+        int n = s_ctl[1] < a.max_det ? s_ctl[1] : a.max_det;
+        n = n < KBL ? n : KBL;
+        for (int pos = tid; pos < n; pos += K3_THREADS) k3_emit(a, b, pos, kb[pos], (int)(uint32_t)keys[kj[pos]], score, bw, wprefix);
     }
     if (tid == 0) {
         const int n = s_ctl[1];
@@ -501,7 +546,8 @@ extern "C" int rva_postprocess_batch(rva_ctx *ctx, const void *raw, int raw_dtyp
     const int nwords = rva_ceil_div(A, 32);
     const int sc = kcap <= 8192 ? 512 : 256;                       // 128 KB of keys leave room for a 256-box round only (sc <= 512:
                                                                    // two threads per box in phase 1)
-    const size_t smem = (size_t)kcap * 8 + (size_t)K3_KBL * 16 + (size_t)sc * 20 + (size_t)sc * (sc / 64) * 8 +
+    const int kbl = kcap <= 8192 ? K3_KBL : K3_KBL / 2;
+    const size_t smem = (size_t)kcap * 8 + (size_t)(kbl + 8) * 16 + (size_t)kbl * 4 + (size_t)sc * 20 + (size_t)sc * (sc / 64) * 8 +
                         (((size_t)nwords * 4 + 15) & ~(size_t)15) + 64 + 128 + 64;
     if (smem > 160 * 1024) return rva_fail(ctx, RVA_ERR_CAPACITY, "post-process: %d anchors need %zu B of LDS", A, smem);
     RVA_HIP(ctx, rva_func_smem((const void *)k3_nms, smem));
@@ -533,7 +579,7 @@ extern "C" int rva_postprocess_batch(rva_ctx *ctx, const void *raw, int raw_dtyp
         K3Args k3{};
         k3.sp_box = (const float4 *)ctx->sp_box; k3.sp_score = ctx->sp_score; k3.sp_cls = ctx->sp_cls;
         k3.bits = ctx->cand_bits;
-        k3.nwords = nwords; k3.A = A; k3.kcap = kcap; k3.sc = sc;
+        k3.nwords = nwords; k3.A = A; k3.kcap = kcap; k3.sc = sc; k3.kbl = kbl;
         k3.iou_thr = (float)iou_thr;
         {   // where rounding leaves thr: midpoint to the next float above, a tie goes to the even mantissa
             const float t = (float)iou_thr;
@@ -541,6 +587,7 @@ extern "C" int rva_postprocess_batch(rva_ctx *ctx, const void *raw, int raw_dtyp
             std::memcpy(&tb, &t, 4);
             k3.sup.m = ((double)t + (double)std::nextafterf(t, INFINITY)) * 0.5;
             k3.sup.tie_incl = (tb & 1u) == 0;
+            k3.sup.thr = t; k3.sup.thr_up = std::nextafterf(t, INFINITY);
         }
         k3.max_det = max_det;
         k3.out_boxes = (float4 *)out_boxes + (size_t)b0 * max_det;
