@@ -167,6 +167,15 @@ __device__ __forceinline__ bool suppresses_fast(const float4 a, const float area
 }
 __device__ __forceinline__ float box_area(const float4 b) { return (b.z - b.x) * (b.w - b.y); }
 
+// a 16-byte load that is a global_load for certain (a flat load would also count as an LDS operation and hold up every LDS wait
+// while it is in flight)
+typedef float k3_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 load_global_f4(const float4 *p)
+{
+    const k3_f4 v = *reinterpret_cast<const __attribute__((address_space(1))) k3_f4 *>(reinterpret_cast<size_t>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 struct K3Args {
     const float4 *sp_box;
     const float *sp_score;
@@ -291,6 +300,7 @@ __global__ void __launch_bounds__(K3_THREADS) k3_nms(K3Args a)
     float4 *sv_box = (float4 *)(k3_smem + off); off += (size_t)SC * 16;     // survivors of phase 1, in order
     int *sv_j = (int *)(k3_smem + off); off += (size_t)SC * 4;              // their position in the sorted list
     int *kj = (int *)(k3_smem + off); off += (size_t)KBL * 4;            // kept boxes so far: position in the sorted list
+    float *ka = (float *)(k3_smem + off); off += (size_t)(KBL + 8) * 4;     // their areas (zero past the list, like the boxes)
     unsigned long long *smask = (unsigned long long *)(k3_smem + off); off += (size_t)SC * (SC / 64) * 8;   // [SC][SC/64]
     int *wprefix = (int *)(k3_smem + off); off += (((size_t)a.nwords * 4 + 15) & ~(size_t)15);             // [nwords]
     int *wave_tot = (int *)(k3_smem + off); off += 64;                       // [16]
@@ -303,7 +313,7 @@ __global__ void __launch_bounds__(K3_THREADS) k3_nms(K3Args a)
     // ---- candidates = set bits of the pass bitmap: exclusive prefix of the word popcounts (512 words per round)
     const uint32_t *bw = a.bits + (long)b * a.nwords;
     if (tid == 0) { s_ctl[1] = 0; s_ctl[2] = 0; }
-    for (int i = tid; i < KBL + 8; i += K3_THREADS) kb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i < KBL + 8; i += K3_THREADS) { kb[i] = make_float4(0.f, 0.f, 0.f, 0.f); ka[i] = 0.f; }
     __syncthreads();
     for (int w0 = 0; w0 < a.nwords; w0 += K3_THREADS) {
         const int w = w0 + tid;
@@ -368,18 +378,24 @@ __global__ void __launch_bounds__(K3_THREADS) k3_nms(K3Args a)
     // reaches the quadratic phase 2 -- 64^2/2 + 128^2/2 + 256^2/2 IoUs instead of 512^2/2 -- and they fill the kept list that
     // lets phase 1 kill most of the later, full-size rounds.
     int rs = 64;
+    const int bt = tid & (K3_THREADS / 2 - 1), half = tid / (K3_THREADS / 2);
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 nbx = bt < rs && bt < K ? load_global_f4(box + (int)(uint32_t)keys[bt]) : zero4;       // the first round's box
     for (int base = 0; base < K; base += rs, rs = rs * 2 < SC ? rs * 2 : SC) {
         // ---- phase 1: a box against everything kept so far; two threads per box (t and t + 512) share the kept list
         // (even / odd groups of four)
-        const int bt = tid & (K3_THREADS / 2 - 1), half = tid / (K3_THREADS / 2);
         const int j = base + bt;
         const bool valid = bt < rs && j < K;
-        const int an = valid ? (int)(uint32_t)keys[j] : 0;
-        const float4 bx = valid ? box[an] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 bx = nbx;
+        const float area_b = box_area(bx);
+        asm volatile("" :: "v"(bx.x), "v"(bx.y), "v"(bx.z), "v"(bx.w), "v"(area_b));      // this round's box has arrived before ...
+        {   // ... the next round's box sets out: it travels while this round works
+            const int nrs = rs * 2 < SC ? rs * 2 : SC, jn = base + rs + bt;
+            nbx = bt < nrs && jn < K ? load_global_f4(box + (int)(uint32_t)keys[jn]) : zero4;
+        }
         bool alive = valid;
         const int nk = s_ctl[1] < a.max_det ? s_ctl[1] : a.max_det;
         const int nk_lds = nk < KBL ? nk : KBL;
-        const float area_b = box_area(bx);
         // four kept boxes per step, branch-free: the (broadcast) LDS reads and the four tests of a step overlap, one
         // early-exit test per step; reads past the list find all-zero boxes
         for (int i = 4 * half; i < nk_lds; i += 8) {
@@ -387,17 +403,19 @@ __global__ void __launch_bounds__(K3_THREADS) k3_nms(K3Args a)
             float4 k4[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) k4[u] = kb[i + u];
+            const float4 a4 = *reinterpret_cast<const float4 *>(ka + i);
+            const float ar[4] = {a4.x, a4.y, a4.z, a4.w};
             bool hit = false, unsure = false;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) hit |= suppresses_fast(k4[u], box_area(k4[u]), bx, area_b, a.sup, unsure);     // detector.py:373
+            for (int u = 0; u < 4; ++u) hit |= suppresses_fast(k4[u], ar[u], bx, area_b, a.sup, unsure);     // detector.py:373
             if (__any(unsure)) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) hit |= suppresses(k4[u], box_area(k4[u]), bx, area_b, a.sup);
+                for (int u = 0; u < 4; ++u) hit |= suppresses(k4[u], ar[u], bx, area_b, a.sup);
             }
             alive = alive && !hit;
         }
         const float4 *kept_glb = a.out_boxes + (long)b * a.max_det;
-        for (int i = KBL + half; i < nk; i += 2) {             // more than 1024 boxes kept in one image: the rest from HBM
+        for (int i = KBL + half; i < nk; i += 2) {             // more boxes kept in one image than the LDS list holds: the rest from HBM
             if (!__any(alive)) break;
             const float4 kg = kept_glb[i];
             alive = alive && !suppresses(kg, box_area(kg), bx, area_b, a.sup);
@@ -418,70 +436,71 @@ __global__ void __launch_bounds__(K3_THREADS) k3_nms(K3Args a)
             sv_box[sidx] = bx;
             sv_j[sidx] = j;
         }
+        if (ns > 64)                                              // words below the diagonal are ORed together in phase 2a
+            for (int x = 64 + tid; x < ns; x += K3_THREADS)
+                for (int t = 0; t < (x >> 6); ++t) smask[(size_t)x * scw + t] = 0ull;
         __syncthreads();
         K3_STAMP(3);
         if (ns == 0) continue;                                    // uniform
-        // ---- phase 2a: suppression matrix of the survivors (row r suppresses column c > r), tiles outer, rows inner
+        // ---- phase 2a: who suppresses whom among the survivors, smask[x][t] = the survivors of tile t (64 of them) that
+        // x and they suppress one another -- the float32 terms of the test are symmetric, so one test per pair fills both
+        // directions: for every pair of tiles rt <= ct a wave takes four rows of rt; lanes are the columns of ct; a row's
+        // ballot is its word for tile ct, and a lane ORs its four answers into its own (zeroed) word for tile rt.
         const int nct = (ns + 63) >> 6;
-        for (int ct = 0; ct < nct; ++ct) {
+        for (int ct = 0, rt = 0; ct < nct; rt == ct ? (++ct, rt = 0) : ++rt) {
             const int col = ct * 64 + lane;
-            const float4 cb = col < ns ? sv_box[col] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 cb = col < ns ? sv_box[col] : zero4;
             const float area_c = box_area(cb);
-            const int rend = (ct + 1) * 64 < ns ? (ct + 1) * 64 : ns;
-            for (int r0 = wave; r0 < rend; r0 += 4 * K3_WAVES) {               // four rows per step (reads in flight together)
-                float4 rb[4];
+            const int rbase = rt * 64 + wave * 4;
+            if (rbase >= ns) continue;                            // wave-uniform
+            float4 rb[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int r = r0 + u * K3_WAVES;
-                    rb[u] = sv_box[r < rend ? r : r0];             // one address for the wave: a broadcast read
-                }
+            for (int u = 0; u < 4; ++u) rb[u] = sv_box[rbase + u < ns ? rbase + u : rbase];      // one address for the wave: a broadcast read
+            unsigned mine = 0u;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int r = r0 + u * K3_WAVES;
-                    if (r < rend) {                                // wave-uniform
-                        bool unsure = false;
-                        bool sup = suppresses_fast(rb[u], box_area(rb[u]), cb, area_c, a.sup, unsure);
-                        if (__any(unsure)) sup = suppresses(rb[u], box_area(rb[u]), cb, area_c, a.sup);
-                        sup = sup && col < ns && col > r;
-                        const unsigned long long w = __ballot(sup);
-                        if (lane == 0) smask[(size_t)r * scw + ct] = w;
-                    }
-                }
+            for (int u = 0; u < 4; ++u) {
+                const int r = rbase + u;
+                bool unsure = false;
+                bool sup = suppresses_fast(rb[u], box_area(rb[u]), cb, area_c, a.sup, unsure);
+                if (__any(unsure)) sup = suppresses(rb[u], box_area(rb[u]), cb, area_c, a.sup);
+                sup = sup && col < ns && r < ns && col != r;
+                const unsigned long long w = __ballot(sup);
+                if (lane == 0 && r < ns) smask[(size_t)r * scw + ct] = w;
+                mine |= (sup ? 1u : 0u) << u;
             }
+            if (rt < ct && mine)
+                __hip_atomic_fetch_or(reinterpret_cast<unsigned *>(&smask[(size_t)col * scw + rt]) + (wave >> 3), mine << ((wave & 7) * 4),
+                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         __syncthreads();
         K3_STAMP(4);
-        // ---- phase 2b: the greedy loop on the matrix, one wave; lane w keeps the removed word of survivor chunk w
+        // ---- phase 2b: the greedy order on the matrix, one wave, 64 survivors per step.  A survivor is out if a box kept in an
+        // earlier step suppresses it; within the step it is kept exactly when no KEPT earlier survivor of the step suppresses it:
+        // settled in passes -- out once such a one is kept, kept once none of them is still open -- the lowest open survivor
+        // settles in every pass, clusters settle in two or three.
         if (wave == 0) {
-            unsigned long long removed = 0ull;
+            unsigned long long keptw = 0ull;                       // lane t: the survivors of tile t that were kept
             int out0 = s_ctl[1];
             for (int c = 0; c < nct; ++c) {
                 const int r = c * 64 + lane;
-                const unsigned long long diag = r < ns ? smask[(size_t)r * scw + c] : 0ull;
-                const unsigned long long rem = readlane64(removed, c);
-                const unsigned long long vm = ns - c * 64 >= 64 ? ~0ull : ((1ull << (ns - c * 64)) - 1ull);
-                unsigned long long al = ~rem & vm, kept = 0ull;
-                while (al) {                                       // scalar walk: next alive survivor is kept and clears its victims
-                    const int l = __builtin_ctzll(al);
-                    kept |= 1ull << l;
-                    al &= ~readlane64(diag, l);
-                    al &= ~(1ull << l);
+                const bool in = r < ns;
+                const unsigned long long own = in ? smask[(size_t)r * scw + c] : 0ull;
+                unsigned long long hitw = 0ull;
+                for (int t = 0; t < c; ++t) hitw |= (in ? smask[(size_t)r * scw + t] : 0ull) & readlane64(keptw, t);
+                const unsigned long long before = own & ((1ull << lane) - 1ull);
+                unsigned long long open = __ballot(in && hitw == 0ull), kept = 0ull;
+                while (open) {
+                    const bool mine = (open >> lane) & 1ull;
+                    const bool out = (before & kept) != 0ull, wait = (before & open) != 0ull;
+                    const unsigned long long nk_ = __ballot(mine && !out && !wait), no_ = __ballot(mine && out);
+                    kept |= nk_;
+                    open &= ~(nk_ | no_);
                 }
-                unsigned long long k2 = kept;
-                const bool later = lane > c && lane < nct;
-                while (k2) {                                       // kept rows suppress survivors of later chunks (four reads in flight)
-                    int l4[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) { l4[q] = k2 ? __builtin_ctzll(k2) : -1; if (k2) k2 &= k2 - 1ull; }
-                    unsigned long long r4[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) r4[q] = (l4[q] >= 0 && later) ? smask[(size_t)(c * 64 + l4[q]) * scw + lane] : 0ull;
-                    removed |= r4[0] | r4[1] | r4[2] | r4[3];
-                }
+                if (lane == c) keptw = kept;
                 if ((kept >> lane) & 1ull) {
                     const int pos = out0 + __popcll(kept & ((1ull << lane) - 1ull));
                     const float4 kbx = sv_box[r];
-                    if (pos < KBL) { kb[pos] = kbx; kj[pos] = sv_j[r]; }      // its output row is written after the last round
+                    if (pos < KBL) { kb[pos] = kbx; ka[pos] = box_area(kbx); kj[pos] = sv_j[r]; }   // its output row is written after the last round
                     else if (pos < a.max_det) k3_emit(a, b, pos, kbx, (int)(uint32_t)keys[sv_j[r]], score, bw, wprefix);
                     if (pos >= a.max_det) atomicOr(a.flags, 1);
                 }
@@ -547,7 +566,7 @@ extern "C" int rva_postprocess_batch(rva_ctx *ctx, const void *raw, int raw_dtyp
     const int sc = kcap <= 8192 ? 512 : 256;                       // 128 KB of keys leave room for a 256-box round only (sc <= 512:
                                                                    // two threads per box in phase 1)
     const int kbl = kcap <= 8192 ? K3_KBL : K3_KBL / 2;
-    const size_t smem = (size_t)kcap * 8 + (size_t)(kbl + 8) * 16 + (size_t)kbl * 4 + (size_t)sc * 20 + (size_t)sc * (sc / 64) * 8 +
+    const size_t smem = (size_t)kcap * 8 + (size_t)(kbl + 8) * 20 + (size_t)kbl * 4 + (size_t)sc * 20 + (size_t)sc * (sc / 64) * 8 +
                         (((size_t)nwords * 4 + 15) & ~(size_t)15) + 64 + 128 + 64;
     if (smem > 160 * 1024) return rva_fail(ctx, RVA_ERR_CAPACITY, "post-process: %d anchors need %zu B of LDS", A, smem);
     RVA_HIP(ctx, rva_func_smem((const void *)k3_nms, smem));
