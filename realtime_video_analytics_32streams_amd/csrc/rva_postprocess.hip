@@ -203,6 +203,10 @@ __device__ unsigned long long g_k3_stamps[64][8];
 
 constexpr int K3_THREADS = 1024;   // 16 waves: four per SIMD hide the LDS / ALU latencies of the IoU loops (two did not)
 constexpr int K3_WAVES = K3_THREADS / 64;
+#ifndef RVA_K3_NEWEST
+#define RVA_K3_NEWEST 64
+#endif
+constexpr int K3_NEWEST = RVA_K3_NEWEST;     // phase 1, stage A: the kept boxes every box of a round is tested against before the round is thinned out
 constexpr int K3_KBL = 1024;       // kept boxes held in LDS for phase 1 at most (K3Args::kbl; further ones are read back from out_boxes)
 
 extern __shared__ __attribute__((aligned(16))) unsigned char k3_smem[];
@@ -396,9 +400,11 @@ __global__ void __launch_bounds__(K3_THREADS) k3_nms(K3Args a)
         bool alive = valid;
         const int nk = s_ctl[1] < a.max_det ? s_ctl[1] : a.max_det;
         const int nk_lds = nk < KBL ? nk : KBL;
-        // four kept boxes per step, branch-free: the (broadcast) LDS reads and the four tests of a step overlap, one
-        // early-exit test per step; reads past the list find all-zero boxes
-        for (int i = 4 * half; i < nk_lds; i += 8) {
+        // Stage A: the K3_NEWEST most recently kept boxes (a box's suppressor scored only a little higher than the box itself,
+        // so it is usually among them).  Four kept boxes per step, branch-free: the (broadcast) LDS reads and the four tests
+        // of a step overlap, one early-exit test per step; reads past the list find all-zero boxes.
+        const int lo = nk_lds > K3_NEWEST ? (nk_lds - K3_NEWEST) & ~7 : 0;        // stage B takes the kept boxes [0, lo)
+        for (int i = lo + 4 * half; i < nk_lds; i += 8) {
             if (!__any(alive)) break;
             float4 k4[4];
 #pragma unroll
@@ -421,7 +427,7 @@ __global__ void __launch_bounds__(K3_THREADS) k3_nms(K3Args a)
             alive = alive && !suppresses(kg, box_area(kg), bx, area_b, a.sup);
         }
         K3_STAMP(2);
-        // ---- survivors (alive in BOTH halves of the kept list), compacted in sorted order by the lower 512 threads
+        // ---- boxes still alive (in BOTH halves of the kept list), compacted in sorted order by the lower 512 threads
         const unsigned long long am0 = __ballot(alive);
         if (lane == 0) half_alive[wave] = am0;
         __syncthreads();
@@ -436,10 +442,55 @@ __global__ void __launch_bounds__(K3_THREADS) k3_nms(K3Args a)
             sv_box[sidx] = bx;
             sv_j[sidx] = j;
         }
-        if (ns > 64)                                              // words below the diagonal are ORed together in phase 2a
+        __syncthreads();
+        // Stage B: what is left (a fraction) against the older kept boxes [0, lo), all 1024 threads again: thread t takes box
+        // t mod mp (mp = the count padded to whole waves) and every (1024 / mp)-th group of four kept boxes; a hit marks the box.
+        if (lo > 0 && ns > 0) {                                   // uniform
+            const int mp = (ns + 63) & ~63, parts = K3_THREADS / mp;
+            const int part = tid / mp, bi = tid - part * mp;      // part is the same for a whole wave
+            bool open = part < parts && bi < ns;
+            const float4 ob = open ? sv_box[bi] : zero4;
+            const float area_o = box_area(ob);
+            for (int i = 4 * part; i < lo; i += 4 * parts) {
+                if (!__any(open)) break;
+                float4 k4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) k4[u] = kb[i + u];
+                const float4 a4 = *reinterpret_cast<const float4 *>(ka + i);
+                const float ar[4] = {a4.x, a4.y, a4.z, a4.w};
+                bool hit = false, unsure = false;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) hit |= suppresses_fast(k4[u], ar[u], ob, area_o, a.sup, unsure);
+                if (__any(unsure)) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) hit |= suppresses(k4[u], ar[u], ob, area_o, a.sup);
+                }
+                if (open && hit) sv_j[bi] = -1;                   // several parts may say so: the same value
+                open = open && !hit;
+            }
+            __syncthreads();
+            // second compaction, in place: every survivor is read before any is written
+            const bool mine = tid < ns;
+            const float4 sb = mine ? sv_box[tid] : zero4;
+            const int sj = mine ? sv_j[tid] : -1;
+            const unsigned long long lm = __ballot(sj >= 0);
+            if (lane == 0) wave_tot[wave] = __popcll(lm);
+            __syncthreads();
+            int so2 = 0, ns2 = 0;
+            for (int q = 0; q < K3_WAVES / 2; ++q) { if (q < wave) so2 += wave_tot[q]; ns2 += wave_tot[q]; }
+            if (sj >= 0) {
+                const int sidx = so2 + __popcll(lm & ((1ull << lane) - 1ull));
+                sv_box[sidx] = sb;
+                sv_j[sidx] = sj;
+            }
+            ns = ns2;
+            __syncthreads();
+        }
+        if (ns > 64) {                                            // words below the diagonal are ORed together in phase 2a
             for (int x = 64 + tid; x < ns; x += K3_THREADS)
                 for (int t = 0; t < (x >> 6); ++t) smask[(size_t)x * scw + t] = 0ull;
-        __syncthreads();
+            __syncthreads();
+        }
         K3_STAMP(3);
         if (ns == 0) continue;                                    // uniform
         // ---- phase 2a: who suppresses whom among the survivors, smask[x][t] = the survivors of tile t (64 of them) that
