@@ -74,9 +74,9 @@ def parse():
                     help="launch every kernel eagerly instead of replaying the captured hipGraph of the post-process / tracker tail")
     ap.add_argument("--net-graph", action="store_true",
                     help="also replay the detector network from a captured hipGraph (serialises its concurrent detect branches)")
-    ap.add_argument("--depth", type=int, default=2, choices=[1, 2],
-                    help="ticks in flight: 2 = tick k+1 is enqueued before tick k's tracks are consumed (GPU never idles "
-                         "on host work); 1 = strictly synchronous ticks (lowest latency)")
+    ap.add_argument("--depth", type=int, default=3, choices=[1, 2, 3, 4],
+                    help="ticks in flight, each a chain on its own HIP stream: 3 (default) measured +3..7 %% frames/s over 2 at "
+                         "+1.6 ms p99 latency, 4 is slower than 2; 1 = strictly synchronous ticks (lowest latency)")
     return ap.parse_args()
 
 
@@ -250,16 +250,13 @@ def main():
         id_sync.sample_every = 4
     barrier()
     t_begin = time.perf_counter()
-    if args.depth == 1:
-        for k in range(K):
-            enqueue(k)
-            n_tracks += finish(k)
-    else:
-        enqueue(0)
-        for k in range(1, K):
-            enqueue(k)
-            n_tracks += finish(k - 1)
-        n_tracks += finish(K - 1)
+    done = 0
+    for k in range(K):                                   # `depth` ticks in flight: collect the oldest before the (depth + 1)-th
+        if k - done == args.depth:
+            n_tracks += finish(done); done += 1
+        enqueue(k)
+    while done < K:
+        n_tracks += finish(done); done += 1
     post = runner.last_post
     torch.cuda.synchronize()
     own_elapsed = time.perf_counter() - t_begin          # this rank alone, before the closing barrier
@@ -345,7 +342,7 @@ def main():
         "p99_latency_ms": round(float(np.percentile(lat, 99)) * 1e3, 3),
         "p50_latency_ms": round(float(np.percentile(lat, 50)) * 1e3, 3),
         "max_latency_ms": round(float(lat.max()) * 1e3, 3), "latency_samples": int(K),
-        "ticks_in_flight": args.depth, "network_streams": runner.net_streams, "warmup_ticks_run": warm_ticks, "hip_graph": bool(use_graph), "hip_graph_scope": ("network + tail" if args.net_graph else ("post-process / tracker tail (networks launched eagerly; a tick is one chain on its own stream, even / odd ticks on two streams)" if runner.net_streams == 2 else "post-process / tracker tail (network launched eagerly: concurrent detect branches)")) if use_graph else None, "realtime_32x30fps": bool(fps / world >= 30.0 * S and np.percentile(lat, 99) < 1 / 30),
+        "ticks_in_flight": args.depth, "network_streams": runner.net_streams, "warmup_ticks_run": warm_ticks, "hip_graph": bool(use_graph), "hip_graph_scope": ("network + tail" if args.net_graph else ("post-process / tracker tail (networks launched eagerly; a tick is one chain on its own stream, consecutive ticks rotate over %d streams)" % runner.net_streams if runner.net_streams >= 2 else "post-process / tracker tail (network launched eagerly: concurrent detect branches)")) if use_graph else None, "realtime_32x30fps": bool(fps / world >= 30.0 * S and np.percentile(lat, 99) < 1 / 30),
         "stages_ms": {"k1_preprocess": round(float(k1_ms), 4), "detector": round(float(net_ms), 4),
                       "k2k3_postprocess": round(float(post_ms), 4), "k4_tracker": round(float(trk_ms), 4)},
         "detections_per_frame": round(dets_emitted / S, 2), "tracks_per_stream": round(n_tracks / (K * S), 2),
@@ -368,6 +365,9 @@ def main():
     if multi is not None:
         out["multi_gpu"] = multi
     out["kernel_selection"] = getattr(det._plans.get((S, 640, 640)), "tuning_source", None)
+    refined = getattr(det._plans.get((S, 640, 640)), "refined", None)
+    if refined:     # what the second pass of the kernel selection (whole forward passes, three in flight) changed: layer, from, to, us before / after
+        out["kernel_selection_refinements"] = [list(r) for r in refined]
     if rank == 0 and not args.no_extras:
         try:
             extras(args, out, sources[:S], rctx, dev, dcfg, tcfg)
@@ -461,14 +461,13 @@ def temporal_main(args, rank, world, local, dev):
         rows += sum(len(v) for v in r.tracks.values())
     barrier()
     t0 = time.perf_counter()
-    if args.depth == 1:
-        for k in range(K):
-            enqueue(k); finish(k)
-    else:
-        enqueue(0)
-        for k in range(1, K):
-            enqueue(k); finish(k - 1)
-        finish(K - 1)
+    done = 0
+    for k in range(K):
+        if k - done == args.depth:
+            finish(done); done += 1
+        enqueue(k)
+    while done < K:
+        finish(done); done += 1
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -679,13 +678,13 @@ def end_to_end_load_sweep(args, sources, rctx, dev, dcfg, tcfg, light_fps):
         K = 150
         lat, t_enq, rows = np.empty(K), np.empty(K), 0
         t0 = time.perf_counter()
-        t_enq[0] = t0
-        runner.submit()
-        for k in range(1, K):
-            t_enq[k] = time.perf_counter()
-            runner.submit()
-            rows += sum(t["n"] for t in runner.collect()[1]); lat[k - 1] = time.perf_counter() - t_enq[k - 1]
-        rows += sum(t["n"] for t in runner.collect()[1]); lat[K - 1] = time.perf_counter() - t_enq[K - 1]
+        done = 0
+        for k in range(K + 1):                               # the same number of ticks in flight as the headline run
+            while done < k and (k == K or k - done == args.depth):
+                rows += sum(t["n"] for t in runner.collect()[1]); lat[done] = time.perf_counter() - t_enq[done]; done += 1
+            if k < K:
+                t_enq[k] = time.perf_counter()
+                runner.submit()
         el = time.perf_counter() - t0
         fps = S * K / el
         legs[f"D{D}"] = {"planted_objects_per_frame": D, "frames_per_s": round(fps, 1), "ms_per_tick": round(el / K * 1e3, 4),

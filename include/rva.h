@@ -247,8 +247,9 @@ int rva_tracker_read_all(rva_tracker *trk, int64_t *ids, int32_t *cls, int32_t *
                          double *conf, double *boxes, int32_t *last_det, int32_t *counts,
                          rva_stream_t stream);
 
+#define RVA_SNAPSHOT_SLOTS 4   /* ticks whose tables may be on their way to the host at once */
 /* Pipelined read-back: snapshot_async enqueues device-to-host copies of every table into pinned
- * staging slot 0 or 1 on `stream` (no host wait); snapshot_fetch (wait != 0) waits for that slot's
+ * staging slot 0 .. RVA_SNAPSHOT_SLOTS - 1 on `stream` (no host wait); snapshot_fetch (wait != 0) waits for that slot's
  * copies only and hands the arrays out ([n_streams, capacity(,4)] like read_all).  Lets tick k+1 be
  * enqueued before tick k's tracks are consumed.  When snapshot_async is captured into a hipGraph no
  * event is recorded: synchronise on the graph launch yourself and call snapshot_fetch with wait = 0. */

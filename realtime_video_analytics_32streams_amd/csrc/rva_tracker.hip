@@ -68,9 +68,9 @@ struct rva_tracker {
     int32_t *processed = nullptr;   // [S] last update: 1 processed, 0 skipped frame, -1 no frame
     // pinned host staging
     int32_t *h_slot = nullptr, *h_offs = nullptr;
-    void *h_read[2] = {nullptr, nullptr};   // pinned snapshot slots
-    void *h_read_dev[2] = {nullptr, nullptr};   // the same slots as the device sees them
-    hipEvent_t snap_done[2] = {nullptr, nullptr};
+    void *h_read[RVA_SNAPSHOT_SLOTS] = {};       // pinned snapshot slots
+    void *h_read_dev[RVA_SNAPSHOT_SLOTS] = {};   // the same slots as the device sees them
+    hipEvent_t snap_done[RVA_SNAPSHOT_SLOTS] = {};
     size_t h_read_bytes = 0;
     hipEvent_t staged = nullptr;  // completion of the last async copy out of h_slot/h_offs
     std::vector<int32_t> gidx_cached;
@@ -595,7 +595,7 @@ int rva_tracker_create(rva_ctx *ctx, int n_streams, int capacity, int max_age, d
     RVA_HIP(ctx, hipHostMalloc(&t->h_offs, (n_streams + 1) * 4));
     RVA_HIP(ctx, hipEventCreateWithFlags(&t->staged, hipEventDisableTiming));
     t->h_read_bytes = sc * (8 + 32 + 8 + 4 + 4 + 4 + 4) + n_streams * 12 + 64 * 12;
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < RVA_SNAPSHOT_SLOTS; ++i) {
         RVA_HIP(ctx, hipHostMalloc(&t->h_read[i], t->h_read_bytes, hipHostMallocMapped));
         RVA_HIP(ctx, hipHostGetDevicePointer(&t->h_read_dev[i], t->h_read[i], 0));
         RVA_HIP(ctx, hipEventCreateWithFlags(&t->snap_done[i], hipEventDisableTiming));
@@ -617,8 +617,11 @@ void rva_tracker_destroy(rva_tracker *t)
     void *dev[] = {t->id, t->box, t->conf, t->cls, t->age, t->hits, t->last_det, t->n_tracks, t->n_new, t->next_id, t->id_ticket, t->flags,
                    t->d_slot, t->d_offs, t->d_gidx, t->d_bscale, t->gate_cfg, t->gate_state, t->emitted, t->processed, t->d_V, t->d_A};
     for (void *p : dev) (void)hipFree(p);
-    void *host[] = {t->h_slot, t->h_offs, t->h_read[0], t->h_read[1]};
-    for (int i = 0; i < 2; ++i) if (t->snap_done[i]) (void)hipEventDestroy(t->snap_done[i]);
+    void *host[] = {t->h_slot, t->h_offs};
+    for (int i = 0; i < RVA_SNAPSHOT_SLOTS; ++i) {
+        if (t->snap_done[i]) (void)hipEventDestroy(t->snap_done[i]);
+        (void)hipHostFree(t->h_read[i]);
+    }
     for (void *p : host) (void)hipHostFree(p);
     if (t->staged) (void)hipEventDestroy(t->staged);
     delete t;
@@ -787,7 +790,7 @@ __global__ void __launch_bounds__(256) k4_snapshot(SnapArgs a)
 
 int rva_tracker_snapshot_async(rva_tracker *t, int slot, rva_stream_t stream_)
 {
-    if (!t || slot < 0 || slot > 1) return RVA_ERR_ARG;
+    if (!t || slot < 0 || slot >= RVA_SNAPSHOT_SLOTS) return RVA_ERR_ARG;
     hipStream_t stream = (hipStream_t)stream_;
     char *h = (char *)t->h_read_dev[slot];
     SnapArgs a{t->id, t->box, t->conf, t->cls, t->age, t->hits, t->last_det, t->n_tracks,
@@ -808,7 +811,7 @@ int rva_tracker_snapshot_async(rva_tracker *t, int slot, rva_stream_t stream_)
 int rva_tracker_snapshot_fetch(rva_tracker *t, int slot, int wait, int64_t *ids, int32_t *cls, int32_t *age,
                                int32_t *hits, double *conf, double *boxes, int32_t *last_det, int32_t *counts)
 {
-    if (!t || slot < 0 || slot > 1) return RVA_ERR_ARG;
+    if (!t || slot < 0 || slot >= RVA_SNAPSHOT_SLOTS) return RVA_ERR_ARG;
     if (wait) RVA_HIP(t->ctx, hipEventSynchronize(t->snap_done[slot]));
     const char *h = (const char *)t->h_read[slot];
     const int32_t *hn = (const int32_t *)(h + snap_off(t, 7));
@@ -831,7 +834,7 @@ int rva_tracker_snapshot_fetch(rva_tracker *t, int slot, int wait, int64_t *ids,
 
 int rva_tracker_snapshot_status(rva_tracker *t, int slot, int32_t *emitted, int32_t *processed, int32_t *flags)
 {
-    if (!t || slot < 0 || slot > 1) return RVA_ERR_ARG;
+    if (!t || slot < 0 || slot >= RVA_SNAPSHOT_SLOTS) return RVA_ERR_ARG;
     const char *h = (const char *)t->h_read[slot];
     if (emitted) std::memcpy(emitted, h + snap_off(t, 8), (size_t)t->n_streams * 4);
     if (processed) std::memcpy(processed, h + snap_off(t, 9), (size_t)t->n_streams * 4);

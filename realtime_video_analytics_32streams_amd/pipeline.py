@@ -366,24 +366,26 @@ class TickPipeline:
 class PipelinedTicks:
     """Throughput mode of :class:`TickPipeline`: ``depth`` ticks in flight, no host round trip inside a tick.
 
-    Default layout (``depth=2``, ``net_streams=2``): a tick is ONE chain on one HIP stream --
+    Default layout (``depth`` >= 2): a tick is ONE chain on one HIP stream --
 
         roi / downsample / K5 motion counts -> per frame group K1 -> detector network (launched eagerly) ->
-        K2/K3 -> K4 (gates decided on the device) -> global ids -> D2H snapshot (slot = tick parity)
+        K2/K3 -> K4 (gates decided on the device) -> global ids -> D2H snapshot (slot = tick mod depth)
 
-    -- and consecutive ticks alternate between two streams, so the forward pass of tick k+1 (stem, 160x160 / 80x80
-    layers) fills the CUs the tail of tick k's pass (20x20 layers, detect branches) leaves idle.  Each parity owns an input
-    tensor, a fused plan (activation buffers), a head tensor and a snapshot slot.  What orders the two chains, by events:
-    K1(k) after K1(k-1) (gate state, source rings); network(k) after the tail of tick k-2 (head tensor and snapshot slot
-    of this parity); tail(k) after tail(k-1) (tracker tables and the shared K2/K3 scratch are touched in tick order);
-    ``collect(k)`` on the tail's event.  With ``use_graph`` the tail (K2/K3 -> K4 [-> ids -> snapshot]) is replayed from a
-    hipGraph captured per parity; a tick shape (which streams are live, their grouping) is captured after it has run
-    eagerly once -- that tick sizes every buffer and sets every kernel attribute outside any capture -- and ticks of
-    another shape run eagerly.  With sharded streams (``pipe.id_sync``) the exchange of new-track counts (RCCL),
-    ``k4_assign_ids`` and the snapshot follow the graph eagerly on the same stream.
+    -- and consecutive ticks rotate over ``depth`` streams (``ops.chain_streams``: one set per process, the same streams for
+    every runner), so the forward pass of tick k+1 (stem, 160x160 / 80x80 layers) fills the CUs the tail of tick k's pass
+    (20x20 layers, detect branches) leaves idle.  ``bench.py`` runs three chains (two: -3..7 % frames/s, four: slower than
+    two).  Each slot owns an input tensor, a fused plan (activation buffers), a head tensor and a snapshot slot.  What
+    orders the chains, by events: K1(k) after K1(k-1) (gate state, source rings); network(k) after the tail of tick k-depth
+    (head tensor and snapshot slot of this slot); tail(k) after tail(k-1) (tracker tables and the shared K2/K3 scratch are
+    touched in tick order); ``collect(k)`` on the tail's event.  With ``use_graph`` the tail (K2/K3 -> K4 [-> ids ->
+    snapshot]) is replayed from a hipGraph captured per slot; a tick shape (which streams are live, their grouping) is
+    captured after it has run eagerly once -- that tick sizes every buffer and sets every kernel attribute outside any
+    capture -- and ticks of another shape run eagerly.  With sharded streams (``pipe.id_sync``) the exchange of new-track
+    counts (RCCL), ``k4_assign_ids`` and the snapshot follow the graph eagerly on the same stream.
 
-    ``net_streams=1`` (or ``RVA_NET_STREAMS=1``) is the older layout: stream A carries K1 + the network with the detect
-    branches forked onto side streams, stream B the tails, released once the next tick's K1 is through.  ``depth=1`` runs
+    ``net_streams=1`` (or ``RVA_NET_STREAMS=1``; two ticks in flight at most) is the older layout: stream A carries K1 + the
+    network with the detect branches forked onto side streams, stream B the tails, released once the next tick's K1 is
+    through.  ``depth=1`` runs
     strictly one tick at a time.  Same results as ``TickPipeline.tick`` in every layout (same kernels, same order per
     stream).  Detectors without a batched device path need the host in the loop and are not supported here.
 
@@ -397,9 +399,10 @@ class PipelinedTicks:
         if any(not hasattr(d, "stage_pre") for d in pipe.detectors):
             raise NotImplementedError("PipelinedTicks needs detectors with a batched device path (stage_pre / stage_net / "
                                       "stage_post); a host-only detector runs through TickPipeline.tick")
-        if depth not in (1, 2):
-            raise ValueError("depth must be 1 or 2 (two snapshot slots, two head tensors)")
+        if depth not in (1, 2, 3, 4):
+            raise ValueError("depth must be 1 .. 4 (snapshot slots of the tracker, motion-count rows of the gate)")
         self.pipe, self.depth = pipe, depth
+        self.nslots = max(depth, 2)           # a tick's slot ("parity") = k mod nslots: buffers, events, snapshot slot
         self.det, self.dt = pipe.detector, pipe.tracker.device_tracker
         self.world_sharded = pipe.id_sync is not None
         is_fused = lambda d: getattr(d, "engine", None) == "fused" and d.half and d._infer_fn is None      # noqa: E731
@@ -417,7 +420,6 @@ class PipelinedTicks:
         # ``overlap=False`` keeps everything on one stream (eager only): the per-stage timing pass of bench.py
         self.two_streams = (overlap or self.use_graph) and chains_ok         # needs per-parity result buffers
         self.sA = torch.cuda.current_stream()
-        self.sB = torch.cuda.Stream(device=self.det.device) if self.two_streams else self.sA
         # The networks of consecutive ticks run on TWO streams (even ticks on A, odd ticks on A'), each with its own input
         # tensor and fused plan: the tail of a forward pass (20x20 layers, detect branches: half the CUs idle) overlaps the
         # head of the next one (stem, 160x160 / 80x80 layers).  Measured with the plan alone: 1.73 -> 1.54 ms per 32-frame
@@ -425,32 +427,39 @@ class PipelinedTicks:
         # rings), and its network for the tick two before it to have released the head tensors of its parity.
         import os
         net_streams = int(os.environ.get("RVA_NET_STREAMS", net_streams))      # A/B switch for measurements
-        self.net_streams = 2 if (net_streams == 2 and self.two_streams and depth == 2 and not self.net_graph) else 1
+        self.net_streams = depth if (net_streams >= 2 and self.two_streams and depth >= 2 and not self.net_graph) else 1
+        if depth > 2 and self.net_streams == 1:
+            raise ValueError("more than two ticks in flight need one chain per tick (fused or two_chain_ok detectors, no net_graph, RVA_NET_STREAMS unset)")
         # Two explicit streams created back to back (the runtime spreads consecutive streams over its hardware queues; the
         # caller's stream may be the null stream, whose queue another stream can share -- then the two networks would
         # serialise: 17.9 k instead of 20.3 k frames/s).  In this mode the plans run their detect branches in line: with two
         # forward passes in flight the side streams add nothing and, spread over more hardware queues, cost up to 25 %
         # (round-2 A/B, DESIGN.md section 4 item 11: 1.53-1.55 ms per pass in line for 3-16 queues, 1.68-1.82 ms with side streams).
-        if self.net_streams == 2:
-            self.sAs = [torch.cuda.Stream(device=self.det.device), torch.cuda.Stream(device=self.det.device)]
+        # The streams come from the process-wide pool (ops.chain_streams): the same ones the kernel selection timed its
+        # overlapping passes on, and the same ones for every runner of the process.
+        if self.net_streams >= 2:
+            self.sAs = ops.chain_streams(self.det.device, self.nslots)
+            self.sB = self.sAs[0]                                  # (tails ride on their tick's own stream in this layout)
         else:
-            self.sAs = [self.sA, self.sA]
+            self.sAs = [self.sA] * self.nslots
+            self.sB = ops.chain_streams(self.det.device, 1)[0] if self.two_streams else self.sA
         # K1 of tick k+1 beside the 20x20 phase of tick k's forward pass (most CUs and most of the HBM bandwidth idle there)
         # instead of beside its stem / 80x80 layers: RVA_K1_GATE=1.  Off by default: see DESIGN.md (K1 in the pipeline).
-        self.k1_gate = os.environ.get("RVA_K1_GATE", "0") == "1" and self.net_streams == 2
-        self._phase_ev = [torch.cuda.Event(), torch.cuda.Event()]
-        self._pending = [None, None]          # per parity: what the stream-B part of that tick needs
-        self._meta = [None, None]             # per parity: (packets, t0) for collect_result
+        self.k1_gate = os.environ.get("RVA_K1_GATE", "0") == "1" and self.net_streams >= 2
+        ns = self.nslots
+        self._phase_ev = [torch.cuda.Event() for _ in range(ns)]
+        self._pending = [None] * ns           # per slot: what the stream-B part of that tick needs
+        self._meta = [None] * ns              # per slot: (packets, t0) for collect_result
         self._next, self._oldest = 0, 0
-        self._done = [torch.cuda.Event(), torch.cuda.Event()]
-        self._net_done = [torch.cuda.Event(), torch.cuda.Event()]
-        self._k1_done = [torch.cuda.Event(), torch.cuda.Event()]
+        self._done = [torch.cuda.Event() for _ in range(ns)]
+        self._net_done = [torch.cuda.Event() for _ in range(ns)]
+        self._k1_done = [torch.cuda.Event() for _ in range(ns)]
         self._posted = -1                     # last tick whose stream-B part has been issued
         self.last_post = None
         self._seen_sigs = set()               # tick shapes that have run eagerly once
         self._cap_sig = None                  # the captured shape
         self._net_graphs: List[List] = []     # [group][parity]
-        self._post_graphs = [None, None]
+        self._post_graphs = [None] * ns
         self._captured = False
 
     # -- pieces of a tick -------------------------------------------------------------------------------------
@@ -458,12 +467,12 @@ class PipelinedTicks:
         plan = det.plan_for(tensor)                                # builds + autotunes the plan of det's current slot (outside any capture)
         # detect branches in line when two passes overlap (see __init__), on side streams when one pass runs at a time
         plan.concurrent_heads = os.environ.get("RVA_SERIAL_HEADS") != "1" and \
-            (self.net_streams != 2 or os.environ.get("RVA_NET2_LANES", "0") == "1")
+            (self.net_streams < 2 or os.environ.get("RVA_NET2_LANES", "0") == "1")
         return plan
 
     def _set_slot(self, par):
         for d in self.pipe.detectors:
-            d._slot = par if self.net_streams == 2 else 0
+            d._slot = par if self.net_streams >= 2 else 0
 
     def _post_part(self, plan, raws, pres, motion, events=None):
         """The tail of one tick for every group: K2/K3 (temporal heads: top-5) then K4 (+ filter, rescale, gates).
@@ -485,7 +494,7 @@ class PipelinedTicks:
     def _ids_and_snapshot(self, k, events=None):
         self.pipe.assign_ids()
         if events: events[4].record()
-        self.dt.snapshot_async(k & 1)
+        self.dt.snapshot_async(k % self.nslots)
 
     def _capture(self, plan, pres, motion):
         """Record the networks (per group and head-tensor parity) and the stream-B part (per parity) of a tick of this
@@ -493,15 +502,15 @@ class PipelinedTicks:
         p = self.pipe
         torch.cuda.synchronize()
         self._net_graphs = []
-        raws = [[None, None] for _ in plan.groups]
+        raws = [[None] * self.nslots for _ in plan.groups]
         for gi, g in enumerate(plan.groups):
             det = p.detectors[g.det]
             pair = []
-            for par in (0, 1):
+            for par in range(self.nslots):
                 self._set_slot(par)
                 fp = self._plan_of(det, pres[gi][0])
                 # head tensor (group, parity): a stable buffer of the plan (two network streams: of the parity's own plan)
-                raws[gi][par] = fp.use_output(gi if self.net_streams == 2 else 2 * gi + par)
+                raws[gi][par] = fp.use_output(gi if self.net_streams >= 2 else 2 * gi + par)
                 if self.net_graph:
                     gr = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(gr):
@@ -510,7 +519,7 @@ class PipelinedTicks:
                     pair.append(gr)
             self._net_graphs.append(pair)
         torch.cuda.synchronize()
-        for par in (0, 1):
+        for par in range(self.nslots):
             mo = None if motion is None else (p._motion_gate().counts[par], motion[1])   # the parity's K5 count row
             gr = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gr):
@@ -524,12 +533,12 @@ class PipelinedTicks:
         self._captured = True
 
     def _issue_post(self, k, after, stream=None):
-        par = k & 1
+        par, prev = k % self.nslots, (k - 1) % self.nslots
         sb = stream if stream is not None else self.sB
         with torch.cuda.stream(sb):
             sb.wait_event(self._net_done[par])
             if stream is not None and k >= 1:
-                sb.wait_event(self._done[par ^ 1])                 # tails on two streams: tracker state is touched in tick order
+                sb.wait_event(self._done[prev])                    # tails on several streams: tracker state is touched in tick order
             if after is not None:
                 sb.wait_event(after)
             mode, plan, raws, pres, motion, events = self._pending[par]
@@ -554,7 +563,7 @@ class PipelinedTicks:
             raise RuntimeError("collect() the oldest tick first")
         p = self.pipe
         k = self._next
-        par = k & 1
+        par, prev = k % self.nslots, (k - 1) % self.nslots
         t0 = time.perf_counter()
         if packets is None:
             packets = [src.next_packet() for src in p.sources]
@@ -562,16 +571,16 @@ class PipelinedTicks:
         sk = sa                                                    # roi / downsample / K5 / K1 ride on the tick's own stream (a separate,
                                                                    # even high-priority, stream for them cost 20 % of the throughput)
         self._set_slot(par)
-        if self.net_streams == 2:
+        if self.net_streams >= 2:
             sa.wait_stream(torch.cuda.current_stream())            # whatever the caller queued before this tick (frame sources)
         with torch.cuda.stream(sk):
-            if self.net_streams == 2:
+            if self.net_streams >= 2:
                 if k >= 1:
-                    sk.wait_event(self._k1_done[par ^ 1])          # the previous tick's K5 / K1 (gate state, source rings) first
-                if k >= 2:
-                    sk.wait_event(self._net_done[par])             # tick k-2's network has read the input tensors of this slot
+                    sk.wait_event(self._k1_done[prev])             # the previous tick's K5 / K1 (gate state, source rings) first
+                if k >= self.nslots:
+                    sk.wait_event(self._net_done[par])             # the slot's previous tick's network has read its input tensors
                 if self.k1_gate and k >= 1:
-                    sk.wait_event(self._phase_ev[par ^ 1])         # ... and tick k-1's forward pass has reached its 20x20 phase
+                    sk.wait_event(self._phase_ev[prev])            # ... and tick k-1's forward pass has reached its 20x20 phase
             packets = p._frames_for_detection(packets)             # roi / downsample (device work)
             plan = p.plan_tick(packets, process)
             motion = p._device_gates(packets, par) if p.has_gates else None       # K5 + gate parameters (no sync)
@@ -591,8 +600,8 @@ class PipelinedTicks:
                 if self.two_streams and gi == len(plan.groups) - 1:
                     self._k1_done[par].record(sk)
             with torch.cuda.stream(sa):
-                if self.two_streams and gi == 0 and k >= 2:
-                    sa.wait_event(self._done[par])                 # tick k-2 has finished reading the head tensors `par`
+                if self.two_streams and gi == 0 and k >= self.nslots:
+                    sa.wait_event(self._done[par])                 # the slot's previous tick has finished reading its head tensors
                 pres.append(pre)
                 if replay and self.net_graph:
                     self._net_graphs[gi][par].replay()
@@ -600,7 +609,7 @@ class PipelinedTicks:
                     with torch.inference_mode():
                         if plan_det and self.two_streams:
                             fp = self._plan_of(det, pre[0])
-                            fp.use_output(gi if self.net_streams == 2 else 2 * gi + par)
+                            fp.use_output(gi if self.net_streams >= 2 else 2 * gi + par)
                             fp.phase_event = self._phase_ev[par] if (self.k1_gate and gi == 0) else None
                         elif plan_det:
                             self._plan_of(det, pre[0])             # sets the plan's branch mode for this runner's layout
@@ -621,7 +630,7 @@ class PipelinedTicks:
         if self.two_streams:
             if self.depth == 1:
                 self._issue_post(k, None)
-            elif self.net_streams == 2 and os.environ.get("RVA_TAIL_INLINE", "1") == "1":
+            elif self.net_streams >= 2 and os.environ.get("RVA_TAIL_INLINE", "1") == "1":
                 # two network streams: the tail goes right behind its own network on the same stream -- a tick is one chain
                 # K1 -> network -> K2/K3 -> K4 -> ids -> snapshot, even and odd ticks on two streams (a third stream for the
                 # tails measured 3 % slower: 19.06 k against 19.70 k frames/s, and made the result depend on how the runtime
@@ -648,11 +657,11 @@ class PipelinedTicks:
         if self.two_streams:
             if self._posted < k:
                 self._issue_post(k, None)                          # no younger tick was submitted: release the tail now
-            self._done[k & 1].synchronize()
-            tables = self.dt.snapshot_fetch(k & 1, wait=False)
+            self._done[k % self.nslots].synchronize()
+            tables = self.dt.snapshot_fetch(k % self.nslots, wait=False)
         else:
-            tables = self.dt.snapshot_fetch(k & 1)                 # tracks visible to the host
-        status = self.dt.snapshot_status(k & 1)
+            tables = self.dt.snapshot_fetch(k % self.nslots)       # tracks visible to the host
+        status = self.dt.snapshot_status(k % self.nslots)
         self._oldest += 1
         return k, tables, status
 
@@ -663,7 +672,7 @@ class PipelinedTicks:
 
     def collect_result(self) -> TickResult:
         k, tables, status = self._collect()
-        packets, t0, clips = self._meta[k & 1]
+        packets, t0, clips = self._meta[k % self.nslots]
         if clips:
             self.pipe._host_dets = dict(clips)
         return self.pipe.finish(packets, tables, status, t0)

@@ -268,9 +268,10 @@ def test_resnet_classifier_topk():
     assert hi.predict(FramePacket(st, frames[0], 0, 0.0)) == []
 
 
-@pytest.mark.parametrize("depth,graph,chains", [(1, False, 1), (2, False, 2), (1, True, 1), (2, True, 2), (2, False, 1), (2, True, 1)],
+@pytest.mark.parametrize("depth,graph,chains", [(1, False, 1), (2, False, 2), (1, True, 1), (2, True, 2), (2, False, 1), (2, True, 1),
+                                                (3, False, 3), (3, True, 3), (4, True, 4)],
                          ids=["d1-eager", "d2-eager-two-chains", "d1-graph", "d2-graph-two-chains", "d2-eager-one-network-stream",
-                              "d2-graph-one-network-stream"])
+                              "d2-graph-one-network-stream", "d3-eager-three-chains", "d3-graph-three-chains", "d4-graph-four-chains"])
 def test_pipelined_ticks_equal_synchronous_ticks(depth, graph, chains):
     """The throughput mode (two ticks in flight, captured hipGraphs; a tick as one chain on its own stream -- even / odd ticks
     on two streams, each with its own input tensor and plan -- or the round-1 layout with one network stream and one stream
@@ -285,7 +286,7 @@ def test_pipelined_ticks_equal_synchronous_ticks(depth, graph, chains):
         s.open_sync()
     runner = PipelinedTicks(TickPipeline(streams, det, trk2, sources=srcs2), depth=depth, use_graph=graph, net_streams=chains)
     assert runner.net_streams == chains
-    T = 7
+    T = 7 if depth <= 2 else 11
     want = []
     for _ in range(T):
         r = sync.tick()
@@ -297,14 +298,18 @@ def test_pipelined_ticks_equal_synchronous_ticks(depth, graph, chains):
         names = [s.name for s in streams]
         tr = trk2.tracks_from_tables(names, [tables[runner.pipe.slots[i]] for i in range(len(streams))])
         got.append({n: [(t.track_id, t.class_id, t.age, t.hits, t.confidence, t.bbox_xyxy) for t in v] for n, v in zip(names, tr)})
-    if depth == 1:
-        for _ in range(T):
-            runner.submit(); take()
-    else:
-        runner.submit()
-        for _ in range(1, T):
-            runner.submit(); take()
-        take()
+    inflight = 0
+    for _ in range(T):
+        if inflight == depth:
+            take(); inflight -= 1
+        runner.submit(); inflight += 1
+    with pytest.raises(RuntimeError):
+        if inflight == depth:
+            runner.submit()                                         # a (depth + 1)-th tick needs a collect() first
+        else:
+            raise RuntimeError
+    while inflight:
+        take(); inflight -= 1
     assert got == want and sum(len(v) for d in got for v in d.values()) > 0
     with pytest.raises(RuntimeError):
         runner.collect()

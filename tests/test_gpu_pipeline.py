@@ -173,15 +173,18 @@ def test_gated_mixed_two_detector_ticks_agree_across_modes():
                 r = pipe.tick(device_gates=(mode == "tick-device"))
                 out.append(({n: _tab(v) for n, v in r.tracks.items()}, dict(r.detections_emitted)))
             return out, pipe
-        runner = PipelinedTicks(pipe, depth=2, use_graph=(mode == "graph"))
-        runner.submit()
-        for _ in range(1, T):
-            runner.submit()
-            r = runner.collect_result()
+        depth = 3 if mode.endswith("3") else 2
+        runner = PipelinedTicks(pipe, depth=depth, use_graph=mode.startswith("graph"))
+        inflight = 0
+        for _ in range(T):
+            if inflight == depth:
+                r = runner.collect_result(); inflight -= 1
+                out.append(({n: _tab(v) for n, v in r.tracks.items()}, dict(r.detections_emitted)))
+            runner.submit(); inflight += 1
+        while inflight:
+            r = runner.collect_result(); inflight -= 1
             out.append(({n: _tab(v) for n, v in r.tracks.items()}, dict(r.detections_emitted)))
-        r = runner.collect_result()
-        out.append(({n: _tab(v) for n, v in r.tracks.items()}, dict(r.detections_emitted)))
-        if mode == "graph":
+        if mode.startswith("graph"):
             assert runner._captured
         return out, pipe
 
@@ -197,7 +200,7 @@ def test_gated_mixed_two_detector_ticks_agree_across_modes():
     want, _ = run("tick-device")
     assert {n: [n in e for _, e in want] for n in pipe.names} == proc
     # throughput mode == synchronous mode, bit for bit (same batches, same kernels, same order per stream)
-    for mode in ("eager", "graph"):
+    for mode in ("eager", "graph", "graph3"):                   # two ticks in flight, and three (three chains on three streams)
         got, _ = run(mode)
         assert got == want, mode
 

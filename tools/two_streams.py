@@ -1,23 +1,26 @@
-"""Experiment: consecutive ticks' forward passes on TWO streams (each tick whole, 32 frames; no dependence between ticks) against one
-stream: does the tail of tick k (20x20 layers, detect branches) overlap the head of tick k+1 (stem, 160x160 / 80x80 layers)?"""
-import sys, time; sys.path.insert(0, ".")
+"""Experiment: consecutive ticks' forward passes on N streams (each tick whole, 32 frames; no dependence between ticks) against one
+stream: does the tail of tick k (20x20 layers, detect branches) overlap the head of tick k+1 (stem, 160x160 / 80x80 layers)?
+usage: python tools/two_streams.py [max streams, default 4]      (plans run their detect branches in line, as in PipelinedTicks)"""
+import os, sys, time; sys.path.insert(0, ".")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import torch
 from realtime_video_analytics_32streams_amd.engine import FusedYoloV8
 from realtime_video_analytics_32streams_amd.yolov8 import build_detector_net
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 net = build_detector_net("s").half().cuda()
-e1, e2 = FusedYoloV8(net, 32), FusedYoloV8(net, 32)
-x = torch.rand((32, 3, 640, 640), device="cuda").half()
-s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
-def run(two, n=60):
+plans = [FusedYoloV8(net, 32) for _ in range(N)]
+for p in plans: p.concurrent_heads = False
+xs = [torch.rand((32, 3, 640, 640), device="cuda").half() for _ in range(N)]
+streams = [torch.cuda.Stream() for _ in range(N)]
+def run(n_streams, n=90):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(n):
-        if two and (i & 1):
-            with torch.cuda.stream(s2): e2(x)
-        else:
-            with torch.cuda.stream(s1): e1(x)
+        j = i % n_streams
+        with torch.cuda.stream(streams[j]): plans[j](xs[j])
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / n * 1e3
-for _ in range(2): run(False, 10); run(True, 10)
-for label, two in (("one stream", False), ("two streams", True), ("one stream", False), ("two streams", True)):
-    print(label, round(run(two), 4), "ms per forward", flush=True)
+for m in range(1, N + 1): run(m, 12)
+for rep in range(2):
+    for m in range(1, N + 1):
+        print(m, "stream(s):", round(run(m), 4), "ms per forward", flush=True)
