@@ -74,9 +74,10 @@ def parse():
                     help="launch every kernel eagerly instead of replaying the captured hipGraph of the post-process / tracker tail")
     ap.add_argument("--net-graph", action="store_true",
                     help="also replay the detector network from a captured hipGraph (serialises its concurrent detect branches)")
-    ap.add_argument("--depth", type=int, default=3, choices=[1, 2, 3, 4],
+    ap.add_argument("--depth", type=int, default=3, choices=[1, 2, 3, 4, 5, 6, 7, 8],
                     help="ticks in flight, each a chain on its own HIP stream: 3 (default) measured +3..7 %% frames/s over 2 at "
-                         "+1.6 ms p99 latency, 4 is slower than 2; 1 = strictly synchronous ticks (lowest latency)")
+                         "+1.6 ms p99 latency; the runtime has four hardware lanes for streams, so a fourth chain shares one with the "
+                         "default stream and is slower than two; 1 = strictly synchronous ticks (lowest latency)")
     return ap.parse_args()
 
 

@@ -247,7 +247,7 @@ int rva_tracker_read_all(rva_tracker *trk, int64_t *ids, int32_t *cls, int32_t *
                          double *conf, double *boxes, int32_t *last_det, int32_t *counts,
                          rva_stream_t stream);
 
-#define RVA_SNAPSHOT_SLOTS 4   /* ticks whose tables may be on their way to the host at once */
+#define RVA_SNAPSHOT_SLOTS 8   /* ticks whose tables may be on their way to the host at once */
 /* Pipelined read-back: snapshot_async enqueues device-to-host copies of every table into pinned
  * staging slot 0 .. RVA_SNAPSHOT_SLOTS - 1 on `stream` (no host wait); snapshot_fetch (wait != 0) waits for that slot's
  * copies only and hands the arrays out ([n_streams, capacity(,4)] like read_all).  Lets tick k+1 be

@@ -82,9 +82,9 @@ class MotionGate:
         self._blur: List[Optional[torch.Tensor]] = [None] * n_streams
         self._have_prev = [False] * n_streams
         self._flip = [0] * n_streams
-        # four count rows: a pipelined caller rotates them per tick (tick k's K4 may still read its counts on another HIP
+        # eight count rows: a pipelined caller rotates them per tick (tick k's K4 may still read its counts on another HIP
         # stream while K5 of the following ticks writes)
-        self.counts = torch.zeros((4, n_streams), dtype=torch.int32, device=self.dev)
+        self.counts = torch.zeros((8, n_streams), dtype=torch.int32, device=self.dev)
         if width is not None and height is not None:                 # geometry known up front (all streams alike)
             for i in range(n_streams):
                 self._blur[i] = torch.empty((2, height, width), dtype=torch.uint8, device=self.dev)

@@ -399,8 +399,8 @@ class PipelinedTicks:
         if any(not hasattr(d, "stage_pre") for d in pipe.detectors):
             raise NotImplementedError("PipelinedTicks needs detectors with a batched device path (stage_pre / stage_net / "
                                       "stage_post); a host-only detector runs through TickPipeline.tick")
-        if depth not in (1, 2, 3, 4):
-            raise ValueError("depth must be 1 .. 4 (snapshot slots of the tracker, motion-count rows of the gate)")
+        if depth not in range(1, 9):
+            raise ValueError("depth must be 1 .. 8 (snapshot slots of the tracker, motion-count rows of the gate)")
         self.pipe, self.depth = pipe, depth
         self.nslots = max(depth, 2)           # a tick's slot ("parity") = k mod nslots: buffers, events, snapshot slot
         self.det, self.dt = pipe.detector, pipe.tracker.device_tracker

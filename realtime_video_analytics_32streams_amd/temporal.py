@@ -222,7 +222,7 @@ class _HipTemporalDetector:
         return self._predict_sequence(name, ring, clip)
 
     # -- batched device path: a whole tick of this head without a host round trip ----------------------------------------
-    RING_EXTRA = 4        # ring slots beyond the clip buffer: up to four ticks may be in flight (K1 of tick k+3 beside the network of k)
+    RING_EXTRA = 8        # ring slots beyond the clip buffer: up to eight ticks may be in flight (K1 of tick k+7 beside the network of k)
 
     @staticmethod
     def geometry_key(frame) -> tuple:
