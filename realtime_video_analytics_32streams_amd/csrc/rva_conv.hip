@@ -1466,6 +1466,13 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BN <= 
     for (int i = 0; i < FN; ++i)
         bvs[i] = *reinterpret_cast<const float4 *>(a.bias + min(n0 + wn * TN + 16 * i + (lane >> 4) * 4, a.CoutPad - 4));
 
+#ifdef RVA_ROW_STAMPS
+    const int st_stride = gridDim.x / 8;
+    const bool st_on = tid == 0 && st_stride > 0 && blockIdx.x % st_stride == 0 && blockIdx.x / st_stride < 8;
+    const int st_slot = st_on ? blockIdx.x / st_stride : 0;
+    int st_n = 0;
+#endif
+    STAMP(0);
     // prologue: the whole run of chunk 0 and the weights of step 0
 #pragma unroll
     for (int k = 0; k < MAXA; ++k)
@@ -1476,9 +1483,12 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BN <= 
     const int wlane = swz32(wn * TN + (lane & 15), lane >> 4);      // this lane's weight row of fragment 0, tap 0
 
     int cc = 0, dy = 0;
+    STAMP(1);
     for (int s = 0; s < nsteps; ++s) {
         wait_vm<0>();                                     // everything this wave issued a step ago has landed ...
+        STAMP(2);
         __builtin_amdgcn_s_barrier();                     // ... and everybody's has; nobody still reads what the next burst overwrites
+        STAMP(3);
         // next step's weights, and this step's third of the NEXT chunk's run
         int ncc = cc, ndy = dy + 1;
         if (ndy == 3) { ndy = 0; ++ncc; }
@@ -1504,6 +1514,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BN <= 
         } while (0)
         const bool early = wv < 4;
         if (early) RUN_ISSUE();
+        STAMP(4);
         const __half *ab = act0 + (size_t)(cc & 1) * apieces * 512;
         const __half *wb = wt0 + (size_t)(s & 1) * WPIECES * 512;
         // Fragment addresses = one swizzled per-lane base per horizontal tap + instruction immediates (16 rows further the
@@ -1541,6 +1552,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BN <= 
 #undef RUN_MFMA
 #undef RUN_ISSUE
         cc = ncc; dy = ndy;
+        STAMP(5);
     }
     __syncthreads();     // all waves done with the buffers: reuse them as the output staging tile
 
@@ -1584,6 +1596,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BN <= 
             *reinterpret_cast<uint4 *>(a.out + (size_t)m * a.ldo + co) = v;
         }
     }
+    STAMP(6);
 }
 
 template <int BM, int BN, int WGM, int WGN>
