@@ -23,7 +23,7 @@ import torch
 
 from . import _native as N
 from . import ops
-from .yolov8 import Bottleneck, C2f, ConvBnAct, SPPF, YoloV8
+from .yolov8 import C2f, ConvBnAct, SPPF, YoloV8
 
 
 def _p(t: torch.Tensor) -> C.c_void_p:

@@ -34,12 +34,11 @@ import time
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
 
-import numpy as np
 import torch
 
 from . import ops
 from .config import PipelineConfig, StreamConfig
-from .detector import Detection, create_detector, filter_detections
+from .detector import create_detector, filter_detections
 from .gates import AdaptiveFps, MotionGate, rasterize_polygons
 from .tracker import IouTracker, Track
 from .video_stream import FramePacket, open_stream
