@@ -361,7 +361,9 @@ def main():
                      "algorithmic_bytes_per_launch": k1_frame_bytes * S, "avg_launch_us": round(float(k1_ms) * 1e3, 2),
                      "avg_launch_us_between_event_records": round(float(k1_bracket_ms) * 1e3, 2),
                      "timing": f"HIP start/stop events of the K1 dispatch itself (hipExtLaunchKernelGGL), every {K1_SAMPLE_EVERY}th timed tick "
-                               "(the event packets cost ~10 us of queue time per use)"},
+                               "(the event packets cost ~10 us of queue time per use); K1 runs beside the forward passes of the other "
+                               "ticks in flight -- alone it takes cold_launch_us, and under rocprofv3 --kernel-trace, which stretches the tick "
+                               "by 40 % and thins out what co-runs, ~20 us (profiles/r03_tick_breakdown.csv)"},
     }
     if multi is not None:
         out["multi_gpu"] = multi
