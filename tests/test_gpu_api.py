@@ -269,9 +269,10 @@ def test_resnet_classifier_topk():
 
 
 @pytest.mark.parametrize("depth,graph,chains", [(1, False, 1), (2, False, 2), (1, True, 1), (2, True, 2), (2, False, 1), (2, True, 1),
-                                                (3, False, 3), (3, True, 3), (4, True, 4)],
+                                                (3, False, 3), (3, True, 3), (4, True, 4), (8, True, 8)],
                          ids=["d1-eager", "d2-eager-two-chains", "d1-graph", "d2-graph-two-chains", "d2-eager-one-network-stream",
-                              "d2-graph-one-network-stream", "d3-eager-three-chains", "d3-graph-three-chains", "d4-graph-four-chains"])
+                              "d2-graph-one-network-stream", "d3-eager-three-chains", "d3-graph-three-chains", "d4-graph-four-chains",
+                              "d8-graph-eight-chains"])
 def test_pipelined_ticks_equal_synchronous_ticks(depth, graph, chains):
     """The throughput mode (two ticks in flight, captured hipGraphs; a tick as one chain on its own stream -- even / odd ticks
     on two streams, each with its own input tensor and plan -- or the round-1 layout with one network stream and one stream
@@ -286,7 +287,7 @@ def test_pipelined_ticks_equal_synchronous_ticks(depth, graph, chains):
         s.open_sync()
     runner = PipelinedTicks(TickPipeline(streams, det, trk2, sources=srcs2), depth=depth, use_graph=graph, net_streams=chains)
     assert runner.net_streams == chains
-    T = 7 if depth <= 2 else 11
+    T = 7 if depth <= 2 else (11 if depth <= 4 else 19)
     want = []
     for _ in range(T):
         r = sync.tick()
