@@ -393,7 +393,7 @@ class PipelinedTicks:
     the :class:`TickResult` instead.  Both raise if the device reported an overflow (tracker capacity / NMS capacity).
     """
 
-    def __init__(self, pipe: TickPipeline, depth: int = 2, use_graph: bool = True, overlap: bool = True,
+    def __init__(self, pipe: TickPipeline, depth: int = 3, use_graph: bool = True, overlap: bool = True,
                  net_graph: bool = False, net_streams: int = 2):
         if any(not hasattr(d, "stage_pre") for d in pipe.detectors):
             raise NotImplementedError("PipelinedTicks needs detectors with a batched device path (stage_pre / stage_net / "
