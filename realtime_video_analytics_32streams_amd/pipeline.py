@@ -428,7 +428,10 @@ class PipelinedTicks:
         net_streams = int(os.environ.get("RVA_NET_STREAMS", net_streams))      # A/B switch for measurements
         self.net_streams = depth if (net_streams >= 2 and self.two_streams and depth >= 2 and not self.net_graph) else 1
         if depth > 2 and self.net_streams == 1:
-            raise ValueError("more than two ticks in flight need one chain per tick (fused or two_chain_ok detectors, no net_graph, RVA_NET_STREAMS unset)")
+            # more than two ticks in flight need one chain per tick (fused or two_chain_ok detectors, no net_graph, RVA_NET_STREAMS
+            # unset); the one-network-stream layout has two head tensors per plan: two ticks in flight
+            self.depth = depth = 2
+            self.nslots = 2
         # Two explicit streams created back to back (the runtime spreads consecutive streams over its hardware queues; the
         # caller's stream may be the null stream, whose queue another stream can share -- then the two networks would
         # serialise: 17.9 k instead of 20.3 k frames/s).  In this mode the plans run their detect branches in line: with two
