@@ -253,7 +253,7 @@ def main():
     t_begin = time.perf_counter()
     done = 0
     for k in range(K):                                   # `depth` ticks in flight: collect the oldest before the (depth + 1)-th
-        if k - done == args.depth:
+        if k - done == runner.depth:
             n_tracks += finish(done); done += 1
         enqueue(k)
     while done < K:
@@ -343,7 +343,7 @@ def main():
         "p99_latency_ms": round(float(np.percentile(lat, 99)) * 1e3, 3),
         "p50_latency_ms": round(float(np.percentile(lat, 50)) * 1e3, 3),
         "max_latency_ms": round(float(lat.max()) * 1e3, 3), "latency_samples": int(K),
-        "ticks_in_flight": args.depth, "network_streams": runner.net_streams, "warmup_ticks_run": warm_ticks, "hip_graph": bool(use_graph), "hip_graph_scope": ("network + tail" if args.net_graph else ("post-process / tracker tail (networks launched eagerly; a tick is one chain on its own stream, consecutive ticks rotate over %d streams)" % runner.net_streams if runner.net_streams >= 2 else "post-process / tracker tail (network launched eagerly: concurrent detect branches)")) if use_graph else None, "realtime_32x30fps": bool(fps / world >= 30.0 * S and np.percentile(lat, 99) < 1 / 30),
+        "ticks_in_flight": runner.depth, "network_streams": runner.net_streams, "warmup_ticks_run": warm_ticks, "hip_graph": bool(use_graph), "hip_graph_scope": ("network + tail" if args.net_graph else ("post-process / tracker tail (networks launched eagerly; a tick is one chain on its own stream, consecutive ticks rotate over %d streams)" % runner.net_streams if runner.net_streams >= 2 else "post-process / tracker tail (network launched eagerly: concurrent detect branches)")) if use_graph else None, "realtime_32x30fps": bool(fps / world >= 30.0 * S and np.percentile(lat, 99) < 1 / 30),
         "stages_ms": {"k1_preprocess": round(float(k1_ms), 4), "detector": round(float(net_ms), 4),
                       "k2k3_postprocess": round(float(post_ms), 4), "k4_tracker": round(float(trk_ms), 4)},
         "detections_per_frame": round(dets_emitted / S, 2), "tracks_per_stream": round(n_tracks / (K * S), 2),
@@ -466,7 +466,7 @@ def temporal_main(args, rank, world, local, dev):
     t0 = time.perf_counter()
     done = 0
     for k in range(K):
-        if k - done == args.depth:
+        if k - done == runner.depth:
             finish(done); done += 1
         enqueue(k)
     while done < K:
@@ -494,7 +494,7 @@ def temporal_main(args, rank, world, local, dev):
                       "decode": "not measured: " + rocdecode_status()},
            "clips_per_s": round(clips / elapsed, 2), "clips_in_timed_region": int(clips),
            "p99_latency_ms": round(float(np.percentile(lat, 99)) * 1e3, 3), "p50_latency_ms": round(float(np.percentile(lat, 50)) * 1e3, 3),
-           "max_latency_ms": round(float(lat.max()) * 1e3, 3), "latency_samples": int(K), "ticks_in_flight": args.depth,
+           "max_latency_ms": round(float(lat.max()) * 1e3, 3), "latency_samples": int(K), "ticks_in_flight": runner.depth,
            "network_streams": runner.net_streams, "warmup_ticks_run": warm, "tracks_per_stream": round(rows / (K * S), 2),
            "realtime_30fps": bool(fps / world >= 30.0 * S and np.percentile(lat, 99) < 1 / 30),
            "roofline": {"kernel": "k1_generic<nv12, clip, float> (3840x2160 NV12 -> fp32 [3,224,224] per stream, stretch resize + "
@@ -683,7 +683,7 @@ def end_to_end_load_sweep(args, sources, rctx, dev, dcfg, tcfg, light_fps):
         t0 = time.perf_counter()
         done = 0
         for k in range(K + 1):                               # the same number of ticks in flight as the headline run
-            while done < k and (k == K or k - done == args.depth):
+            while done < k and (k == K or k - done == runner.depth):
                 rows += sum(t["n"] for t in runner.collect()[1]); lat[done] = time.perf_counter() - t_enq[done]; done += 1
             if k < K:
                 t_enq[k] = time.perf_counter()
