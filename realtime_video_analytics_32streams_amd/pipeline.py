@@ -444,7 +444,7 @@ class PipelinedTicks:
             self.sB = self.sAs[0]                                  # (tails ride on their tick's own stream in this layout)
         else:
             self.sAs = [self.sA] * self.nslots
-            self.sB = ops.chain_streams(self.det.device, 1)[0] if self.two_streams else self.sA
+            self.sB = torch.cuda.Stream(device=self.det.device) if self.two_streams else self.sA
         # K1 of tick k+1 beside the 20x20 phase of tick k's forward pass (most CUs and most of the HBM bandwidth idle there)
         # instead of beside its stem / 80x80 layers: RVA_K1_GATE=1.  Off by default: see DESIGN.md (K1 in the pipeline).
         self.k1_gate = os.environ.get("RVA_K1_GATE", "0") == "1" and self.net_streams >= 2
