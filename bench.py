@@ -74,10 +74,12 @@ def parse():
                     help="launch every kernel eagerly instead of replaying the captured hipGraph of the post-process / tracker tail")
     ap.add_argument("--net-graph", action="store_true",
                     help="also replay the detector network from a captured hipGraph (serialises its concurrent detect branches)")
-    ap.add_argument("--depth", type=int, default=3, choices=[1, 2, 3, 4, 5, 6, 7, 8],
+    ap.add_argument("--depth", type=int, default=None, choices=[1, 2, 3, 4, 5, 6, 7, 8],
                     help="ticks in flight, each a chain on its own HIP stream: 3 (default) measured +3..7 %% frames/s over 2 at "
                          "+1.6 ms p99 latency; the runtime has four hardware lanes for streams, so a fourth chain shares one with the "
-                         "default stream and is slower than two; 1 = strictly synchronous ticks (lowest latency)")
+                         "default stream and is slower than two; 1 = strictly synchronous ticks (lowest latency).  Default: 3 on one GPU, "
+                         "2 with sharded streams (--gpus N > 1): the collective's own stream is a fifth stream, measured -15 %% with three "
+                         "chains and 0 %% with two (profiles/r03_experiments_not_kept.txt #14)")
     return ap.parse_args()
 
 
@@ -139,6 +141,8 @@ def main():
     rank, world, local = rdist.init_from_env()
     if world != args.gpus:
         raise SystemExit(f"bench.py: WORLD_SIZE={world} from the launcher but --gpus {args.gpus}; they must agree")
+    if args.depth is None:      # three tick chains on one GPU; with sharded streams the collective brings a stream of its own: two
+        args.depth = 3 if world == 1 else 2
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP hot path has no CPU fallback")
     if os.environ.get("RVA_SHARE_GPU") != "1" and torch.cuda.device_count() <= local:
@@ -193,6 +197,26 @@ def main():
     tcfg = TrackerConfig(max_age=30, max_iou_distance=0.5, min_hits=1)
     trk = IouTracker(tcfg, max_streams=S, capacity=1024, device=local)
     id_sync = rdist.IdSync(S, dev) if world > 1 else None
+    if world == 1 and os.environ.get("RVA_FIFTH_STREAM"):
+        # experiment (profiles/r03_experiments_not_kept.txt #14): the id exchange as ProcessGroupNCCL would issue it -- a tiny kernel on
+        # a stream of its own, event-ordered behind the tick's K4 and in front of its id assignment -- on a single GPU
+        class _FifthStream(rdist.IdSync):
+            def __init__(self, per, device, early):
+                super().__init__(per, device)
+                self.s = torch.cuda.Stream(device=device)
+                if early:                                   # first use before the chains' streams exist
+                    with torch.cuda.stream(self.s):
+                        self.buf.zero_()
+                    torch.cuda.synchronize()
+
+            def _gather(self, local_counts):
+                cur = torch.cuda.current_stream()
+                self.s.wait_stream(cur)
+                with torch.cuda.stream(self.s):
+                    self.buf[: self.per].copy_(local_counts)
+                cur.wait_stream(self.s)
+                return self.buf
+        id_sync = _FifthStream(S, dev, os.environ["RVA_FIFTH_STREAM"] == "early")
     pipe = TickPipeline(streams, det, trk, sources=sources, id_sync=id_sync, first_global_index=first,
                         n_global_streams=world * S)
     ops.context(local)
@@ -428,6 +452,26 @@ def temporal_main(args, rank, world, local, dev):
     tcfg = TrackerConfig(max_age=30, max_iou_distance=0.5, min_hits=1)
     trk = IouTracker(tcfg, max_streams=S, capacity=256, device=local)
     id_sync = rdist.IdSync(S, dev) if world > 1 else None
+    if world == 1 and os.environ.get("RVA_FIFTH_STREAM"):
+        # experiment (profiles/r03_experiments_not_kept.txt #14): the id exchange as ProcessGroupNCCL would issue it -- a tiny kernel on
+        # a stream of its own, event-ordered behind the tick's K4 and in front of its id assignment -- on a single GPU
+        class _FifthStream(rdist.IdSync):
+            def __init__(self, per, device, early):
+                super().__init__(per, device)
+                self.s = torch.cuda.Stream(device=device)
+                if early:                                   # first use before the chains' streams exist
+                    with torch.cuda.stream(self.s):
+                        self.buf.zero_()
+                    torch.cuda.synchronize()
+
+            def _gather(self, local_counts):
+                cur = torch.cuda.current_stream()
+                self.s.wait_stream(cur)
+                with torch.cuda.stream(self.s):
+                    self.buf[: self.per].copy_(local_counts)
+                cur.wait_stream(self.s)
+                return self.buf
+        id_sync = _FifthStream(S, dev, os.environ["RVA_FIFTH_STREAM"] == "early")
     pipe = TickPipeline(streams, det, trk, sources=sources, id_sync=id_sync, first_global_index=first, n_global_streams=world * S)
     runner = PipelinedTicks(pipe, depth=args.depth)
     rctx = ops.context(local)

@@ -393,11 +393,16 @@ class PipelinedTicks:
     the :class:`TickResult` instead.  Both raise if the device reported an overflow (tracker capacity / NMS capacity).
     """
 
-    def __init__(self, pipe: TickPipeline, depth: int = 3, use_graph: bool = True, overlap: bool = True,
+    def __init__(self, pipe: TickPipeline, depth: Optional[int] = None, use_graph: bool = True, overlap: bool = True,
                  net_graph: bool = False, net_streams: int = 2):
         if any(not hasattr(d, "stage_pre") for d in pipe.detectors):
             raise NotImplementedError("PipelinedTicks needs detectors with a batched device path (stage_pre / stage_net / "
                                       "stage_post); a host-only detector runs through TickPipeline.tick")
+        if depth is None:
+            # three chains; two when the streams are sharded over GPUs: the id exchange runs on the process group's own stream, a
+            # fifth stream on a runtime with four stream lanes (measured with a stand-in on one GPU: -15 % with three chains,
+            # 0 % with two; profiles/r03_experiments_not_kept.txt #14)
+            depth = 3 if pipe.id_sync is None else 2
         if depth not in range(1, 9):
             raise ValueError("depth must be 1 .. 8 (snapshot slots of the tracker, motion-count rows of the gate)")
         self.pipe, self.depth = pipe, depth
