@@ -77,9 +77,10 @@ def parse():
     ap.add_argument("--depth", type=int, default=None, choices=[1, 2, 3, 4, 5, 6, 7, 8],
                     help="ticks in flight, each a chain on its own HIP stream: 3 (default) measured +3..7 %% frames/s over 2 at "
                          "+1.6 ms p99 latency; the runtime has four hardware lanes for streams, so a fourth chain shares one with the "
-                         "default stream and is slower than two; 1 = strictly synchronous ticks (lowest latency).  Default: 3 on one GPU, "
-                         "2 with sharded streams (--gpus N > 1): the collective's own stream is a fifth stream, measured -15 %% with three "
-                         "chains and 0 %% with two (profiles/r03_experiments_not_kept.txt #14)")
+                         "default stream and is slower than two; 1 = strictly synchronous ticks (lowest latency).  Default 3, also with "
+                         "sharded streams: this torch launches a synchronous collective on the CURRENT stream, so the id all-gather brings "
+                         "no stream of its own (a fifth stream would cost three chains 15 %%: profiles/r03_experiments_not_kept.txt #14 "
+                         "-- use --depth 2 if a SCALE record shows per-rank rates well under the single-GPU figure)")
     return ap.parse_args()
 
 
@@ -141,8 +142,8 @@ def main():
     rank, world, local = rdist.init_from_env()
     if world != args.gpus:
         raise SystemExit(f"bench.py: WORLD_SIZE={world} from the launcher but --gpus {args.gpus}; they must agree")
-    if args.depth is None:      # three tick chains on one GPU; with sharded streams the collective brings a stream of its own: two
-        args.depth = 3 if world == 1 else 2
+    if args.depth is None:
+        args.depth = 3
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP hot path has no CPU fallback")
     if os.environ.get("RVA_SHARE_GPU") != "1" and torch.cuda.device_count() <= local:

@@ -399,10 +399,11 @@ class PipelinedTicks:
             raise NotImplementedError("PipelinedTicks needs detectors with a batched device path (stage_pre / stage_net / "
                                       "stage_post); a host-only detector runs through TickPipeline.tick")
         if depth is None:
-            # three chains; two when the streams are sharded over GPUs: the id exchange runs on the process group's own stream, a
-            # fifth stream on a runtime with four stream lanes (measured with a stand-in on one GPU: -15 % with three chains,
-            # 0 % with two; profiles/r03_experiments_not_kept.txt #14)
-            depth = 3 if pipe.id_sync is None else 2
+            # three chains, also with sharded streams: torch >= 2.8 launches a synchronous collective (async_op=False, as IdSync
+            # issues it) on the CURRENT stream, so the id all-gather rides on the tick's own chain.  A collective on a stream of
+            # its own would be a fifth stream on a runtime with four stream lanes: -15 % with three chains, 0 % with two (measured
+            # with a stand-in on one GPU, profiles/r03_experiments_not_kept.txt #14) -- pass depth=2 on such a stack.
+            depth = 3
         if depth not in range(1, 9):
             raise ValueError("depth must be 1 .. 8 (snapshot slots of the tracker, motion-count rows of the gate)")
         self.pipe, self.depth = pipe, depth
