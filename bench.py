@@ -102,6 +102,13 @@ def k1_bytes(w, h, content_only=True, dst=640):
     return rows_in * w + out
 
 
+def input_ring_frames(streams, w, h, cache_bytes=256 << 20):
+    """Frames per stream in the synthetic input ring: one tick's surfaces (streams x pitch x 1.5 h bytes) must not survive to
+    their reuse in a ``cache_bytes`` last-level cache -> at least 2 x cache_bytes of other surfaces in between."""
+    per_tick = streams * ((w + 255) // 256 * 256) * (h + h // 2)
+    return int(min(max(2, -(-2 * cache_bytes // per_tick) + 1), 64))
+
+
 def spawn_ranks(args) -> int:
     """``python bench.py --gpus N`` without a launcher: start N fresh rank processes (one per GPU) and relay rank 0's
     JSON line.  Runs BEFORE anything touches the GPU in this process (``torch.cuda.device_count()`` does not initialise
@@ -172,8 +179,12 @@ def main():
     first = rank * S
     streams = [StreamConfig(name=f"cam{first + i:03d}", url=f"synthetic://{args.width}x{args.height}", target_fps=30.0,
                             warmup_seconds=0.0) for i in range(S)]
-    sources = [SyntheticNv12Stream(s, index=first + i, width=args.width, height=args.height, n_unique=2, device=dev)
-               for i, s in enumerate(streams)]
+    # Input rings sized so that K1 reads HBM, not the 256 MiB Infinity Cache: a frame comes round again only after more than
+    # 2 x 256 MiB of OTHER surfaces have been read (a decoder delivers new bytes every tick).  Two host-generated frames per
+    # stream, the rest derived on the device (SyntheticNv12Stream.ring_frames).
+    ring_frames = input_ring_frames(S, args.width, args.height)
+    sources = [SyntheticNv12Stream(s, index=first + i, width=args.width, height=args.height, n_unique=2, device=dev,
+                                   ring_frames=ring_frames) for i, s in enumerate(streams)]
     for src in sources:
         src.open_sync()
 
@@ -384,6 +395,8 @@ def main():
                      "frac": round(k1_gbs / HBM_PEAK_GBS, 4), "traffic": k1_traffic,
                      "traffic_source": "profiles/r03_k1_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; not collectable while timing)" if k1_traffic else None,
                      "algorithmic_bytes_per_launch": k1_frame_bytes * S, "avg_launch_us": round(float(k1_ms) * 1e3, 2),
+                     "inputs": f"ring of {ring_frames} surfaces per stream ({ring_frames * S * ((args.width + 255) // 256 * 256) * args.height * 3 // 2 >> 20} MiB "
+                               "in all): a surface is read again only after > 2 x 256 MiB of other surfaces, so K1 reads HBM, not the Infinity Cache",
                      "avg_launch_us_between_event_records": round(float(k1_bracket_ms) * 1e3, 2),
                      "timing": f"HIP start/stop events of the K1 dispatch itself (hipExtLaunchKernelGGL), every {K1_SAMPLE_EVERY}th timed tick "
                                "(the event packets cost ~10 us of queue time per use); K1 runs beside the forward passes of the other "
@@ -399,6 +412,16 @@ def main():
     if rank == 0 and not args.no_extras:
         try:
             extras(args, out, sources[:S], rctx, dev, dcfg, tcfg)
+            if world == 1:
+                # what the metric names: a real percentile over >= 300 saturated ticks whatever --steps was, and
+                # the deployment itself -- one tick per 33.33 ms from a host timer on an otherwise idle GPU
+                out["long_run"] = long_run_leg(runner, S, lat if K >= 300 else None, elapsed if K >= 300 else None)
+                if K < 300:     # the headline percentile is a percentile: taken from the >= 300-tick leg, the short region's kept beside it
+                    out["p99_latency_ms_timed_region"], out["latency_samples_timed_region"] = out["p99_latency_ms"], int(K)
+                    out["p99_latency_ms"], out["p50_latency_ms"] = out["long_run"]["p99_ms"], out["long_run"]["p50_ms"]
+                    out["max_latency_ms"], out["latency_samples"] = out["long_run"]["max_ms"], out["long_run"]["ticks"]
+                    out["latency_source"] = "long_run (saturated ticks after the timed region, same runner)"
+                out["paced_30fps"] = paced_leg(args, det, sources[:S], streams, tcfg, fps)
         except Exception as exc:  # noqa: BLE001  -- the measurements after the timed region never cost the headline line
             import traceback
             traceback.print_exc()
@@ -410,6 +433,77 @@ def main():
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+
+
+def _percentiles(lat_s):
+    lat_ms = np.asarray(lat_s) * 1e3
+    return {"p50_ms": round(float(np.percentile(lat_ms, 50)), 3), "p99_ms": round(float(np.percentile(lat_ms, 99)), 3),
+            "p999_ms": round(float(np.percentile(lat_ms, 99.9)), 3), "max_ms": round(float(lat_ms.max()), 3)}
+
+
+def long_run_leg(runner, S, lat=None, elapsed=None, K=320):
+    """p99 over >= 9 600 frame latencies: >= 300 saturated light-load ticks through the headline's own runner
+    (same ticks in flight); a frame's latency is its tick's (enqueue -> tracks on the host).  Reuses the timed region when
+    --steps already gave that many."""
+    reused = lat is not None
+    if not reused:
+        lat, t_enq, done = np.empty(K), np.empty(K), 0
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(K):
+            if k - done == runner.depth:
+                runner.collect(); lat[done] = time.perf_counter() - t_enq[done]; done += 1
+            t_enq[k] = time.perf_counter()
+            runner.submit()
+        while done < K:
+            runner.collect(); lat[done] = time.perf_counter() - t_enq[done]; done += 1
+        elapsed = time.perf_counter() - t0
+    K = len(lat)
+    return {"ticks": int(K), "frame_latency_samples": int(K * S), "ticks_in_flight": runner.depth,
+            "frames_per_s": round(S * K / elapsed, 1), **_percentiles(lat),
+            "source": "the timed region itself" if reused else f"{K} further saturated ticks after the timed region (same runner)"}
+
+
+def paced_leg(args, det, sources, streams, tcfg, saturated_fps, ticks=300, period=1.0 / 30.0):
+    """The operating point the metric names: S streams at 30 fps -- one tick every 33.33 ms from a host timer, the GPU idle
+    (and free to drop its clocks) in between, as a deployment that paces with sleep(1 / target_fps) sees it
+    (reference: video_stream.py:241-243, pipeline.py:143-212).  Latency = timer fires (the tick's surfaces are ready) ->
+    tracks of that tick on the host.  The tick is collected as soon as it is done; `chains` only says how many tick slots
+    (streams, plans, snapshot slots) the runner rotates over."""
+    from realtime_video_analytics_32streams_amd.pipeline import PipelinedTicks, TickPipeline
+    from realtime_video_analytics_32streams_amd.tracker import IouTracker
+    S = len(sources)
+    legs = {}
+    for chains in (1, 3):
+        trk = IouTracker(tcfg, max_streams=S, capacity=1024, device=det.device.index)
+        pipe = TickPipeline(streams, det, trk, sources=sources)
+        runner = PipelinedTicks(pipe, depth=chains, use_graph=not args.no_graph)
+        for _ in range(12):                                   # sizes buffers, captures the graphs
+            runner.submit(); runner.collect()
+        torch.cuda.synchronize()
+        lat = np.empty(ticks)
+        late = 0
+        t0 = time.perf_counter() + 0.05
+        for k in range(ticks):
+            due = t0 + k * period
+            while True:
+                now = time.perf_counter()
+                if now >= due:
+                    break
+                if due - now > 1.5e-3:
+                    time.sleep(due - now - 1e-3)              # sleep to within a millisecond, spin the rest
+            late += now - due > 1e-3
+            runner.submit()
+            runner.collect()
+            lat[k] = time.perf_counter() - due                # from the moment the surfaces were due, timer jitter included
+        legs[f"chains_{chains}"] = {"ticks": ticks, "frame_latency_samples": ticks * S, **_percentiles(lat),
+                                    "timer_fired_late_over_1ms": int(late)}
+        del runner, pipe, trk
+    worst = max(v["p99_ms"] for v in legs.values())
+    return {"streams": S, "tick_period_ms": round(period * 1e3, 3), "what": paced_leg.__doc__.split("\n")[0].strip(),
+            **legs, "p99_under_33ms": bool(worst < period * 1e3),
+            "stream_sets_that_fit": round(saturated_fps / (S * 30.0), 2),
+            "stream_sets_note": f"saturated frames/s of the timed region / ({S} streams x 30 fps)"}
 
 
 def clip_k1_bytes(w, h, dst, out_bytes):
@@ -442,7 +536,8 @@ def temporal_main(args, rank, world, local, dev):
     S = 8 if args.streams == 32 else args.streams
     first = rank * S
     streams = [StreamConfig(name=f"uhd{first + i:03d}", url=f"synthetic://{W}x{H}", target_fps=30.0, warmup_seconds=0.0) for i in range(S)]
-    sources = [SyntheticNv12Stream(s, index=first + i, width=W, height=H, n_unique=2, device=dev) for i, s in enumerate(streams)]
+    sources = [SyntheticNv12Stream(s, index=first + i, width=W, height=H, n_unique=2, device=dev,
+                                   ring_frames=input_ring_frames(S, W, H)) for i, s in enumerate(streams)]
     for src in sources:
         src.open_sync()
     dcfg = DetectorConfig(model_path="cnn_lstm_kinetics400.onnx", backend="hip", model_type="cnn_lstm", sequence_length=16,

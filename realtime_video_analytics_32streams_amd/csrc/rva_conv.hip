@@ -1618,6 +1618,205 @@ hipError_t launch_run(RunArgs &a, hipStream_t s)
 }
 
 // ---------------------------------------------------------------------------------------------------
+// 3x3 stride-1 convolution, "whole chunk per barrier" LDS-DMA variant (round 4) for layers with FEW pixels.
+//
+// Where k_conv3_run pays off it is because a 256 x 128 tile has ~1.5 k cycles of MFMA work per (chunk, dy) step to set
+// against the ~1 k cycles of wait -> barrier -> issue that every step costs.  The small-M layers have no such tiles: at
+// batch 4 (one GPU's share of BASELINE configs[3]) YOLOv8m's 192 -> 192 convolution at 40 x 40 is 6 400 pixels -- 150
+// workgroups of 128 x 64, each walking 54 (chunk, dy) steps of 12 MFMAs per wave at ~600 cycles per step: 18.4 us per
+// launch against a 1.7 us MFMA floor, seventeen times per forward pass (profiles/r04_m4_conv_tuning.txt).  What bounds
+// such a launch is steps x step latency, so this kernel makes the step fat: ONE barrier per 32-channel chunk.  A step
+// stages the chunk's activation run (as k_conv3_run does, once for all nine taps) AND the chunk's weights for all nine
+// taps ([9][BN] rows of 64 B), both double-buffered across chunks, and runs dy x dx = 9 taps of MFMAs between two
+// barriers: Cin / 32 steps instead of 3 Cin / 32.  LDS: 2 x (run + 9 BN / 16) KiB -- 92-150 KB, one workgroup per CU,
+// which costs nothing where the grid has fewer workgroups than the chip has CUs.  BN = 96 exists for YOLOv8m, whose widths
+// (48 / 96 / 192 / 288 / 384 / 576) are multiples of 96, not of 128.  Same K order (chunk, dy, dx), same fp32 accumulation, same
+// epilogue as k_conv3_run.  Needs Cin % 32 == 0 and W <= 160.
+template <int BM, int BN, int WGM, int WGN>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) k_conv3_chunk(RunArgs a)
+{
+    static_assert(WGM * WGN == 8, "eight waves");
+    constexpr int TM = BM / WGM, TN = BN / WGN, FM = TM / 16, FN = TN / 16;
+    static_assert(TM % 16 == 0 && TN % 16 == 0, "whole fragments per wave");
+    constexpr int WPIECES = 9 * BN / 16;                  // weights [9 taps][BN] rows of one chunk
+    constexpr int NPW = (WPIECES + 7) / 8;
+    constexpr int MAXA = 5;                               // activation pieces per wave: ceil((BM + 2*160 + 2) / 16 / 8) for BM <= 256
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv % WGM, wn = wv / WGM;
+    const int n_tile = (blockIdx.x >> 3) % a.n_tiles, m_tile = ((blockIdx.x >> 3) / a.n_tiles) * 8 + (blockIdx.x & 7);   // XCD-aware, see k_conv3_big
+    if (m_tile >= a.m_tiles) return;
+    const int P0 = m_tile * BM, n0 = n_tile * BN;
+    const int HW = a.H * a.W;
+    const int cpt = a.Cin >> 5;
+    const int wrow = 9 * a.Cin;
+    const int apieces = a.apieces;                        // ceil((BM + 2W + 2) / 16)
+    __half *act0 = (__half *)smem;                        // [2][apieces][16][32]
+    __half *wt0 = act0 + (size_t)2 * apieces * 512;       // [2][WPIECES][16][32]
+    const unsigned lds_act = lds_addr(act0), lds_w = lds_addr(wt0);
+
+    const int lrow = lane >> 2, lp = lane & 3;
+    unsigned aoff[MAXA], woff[NPW];
+#pragma unroll
+    for (int k = 0; k < MAXA; ++k) {
+        const int r = (wv + 8 * k) * 16 + lrow;           // row of the run
+        const int q = min(max(P0 - a.W - 1 + r, 0), a.M - 1);
+        aoff[k] = (unsigned)q * (unsigned)(a.ldi * 2) + (unsigned)(((lp - 2 * (r >> 2)) & 3) * 16);
+    }
+#pragma unroll
+    for (int k = 0; k < NPW; ++k) {
+        const int rw = (wv + 8 * k) * 16 + lrow;          // row of the [9][BN] weight image
+        const int tap = min(rw / BN, 8), co = min(n0 + rw - tap * BN, a.CoutPad - 1);
+        woff[k] = (unsigned)(co * wrow + tap * a.Cin) * 2u + (unsigned)(((lp - 2 * (rw >> 2)) & 3) * 16);
+    }
+    int vm[FM];                                           // 9-bit tap validity per pixel fragment
+#pragma unroll
+    for (int j = 0; j < FM; ++j) {
+        const int p = P0 + wm * TM + 16 * j + (lane & 15);
+        int m = 0;
+        if (p < a.M) {
+            const int rem = p % HW, oy = rem / a.W, ox = rem - oy * a.W;
+            const int hv = (ox >= 1 ? 1 : 0) | 2 | (ox <= a.W - 2 ? 4 : 0);
+            m = (oy >= 1 ? hv : 0) | (hv << 3) | (oy <= a.H - 2 ? hv << 6 : 0);
+        }
+        vm[j] = m;
+    }
+    f4 acc[FN][FM];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+    const h8 hz = {0, 0, 0, 0, 0, 0, 0, 0};
+    float4 bvs[FN];                                       // before the first DMA (see k_conv3_big)
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+        bvs[i] = *reinterpret_cast<const float4 *>(a.bias + min(n0 + wn * TN + 16 * i + (lane >> 4) * 4, a.CoutPad - 4));
+
+#define CHUNK_ISSUE(CC)                                                                                          \
+    do {                                                                                                         \
+        const char *ab_ = (const char *)a.in + (CC) * 64;                                                        \
+        const char *wb_ = (const char *)a.w + (CC) * 64;                                                         \
+        const unsigned la_ = lds_act + (unsigned)((CC) & 1) * (unsigned)(apieces * 1024);                        \
+        const unsigned lw_ = lds_w + (unsigned)((CC) & 1) * (unsigned)(WPIECES * 1024);                          \
+        _Pragma("unroll") for (int k = 0; k < NPW; ++k)                                                          \
+            if (wv + 8 * k < WPIECES) lds_dma16(woff[k], wb_, lw_ + (unsigned)(wv + 8 * k) * 1024u);             \
+        _Pragma("unroll") for (int k = 0; k < MAXA; ++k)                                                         \
+            if (wv + 8 * k < apieces) lds_dma16(aoff[k], ab_, la_ + (unsigned)(wv + 8 * k) * 1024u);             \
+    } while (0)
+    CHUNK_ISSUE(0);
+    // per-lane fragment bases, fixed for the whole kernel: the run row of the lane's first pixel for each of the nine taps
+    // (swizzled; 16 rows further the rotation repeats, so the other fragments are immediates) and its first weight row
+    const int ch = lane >> 4;
+    int abase[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) abase[t] = swz32(wm * TM + (lane & 15) + (t / 3) * a.W + (t % 3), ch);
+    const int wlane = swz32(wn * TN + (lane & 15), ch);
+
+    for (int cc = 0; cc < cpt; ++cc) {
+        wait_vm<0>();                                     // this wave's pieces of chunk cc have landed ...
+        __builtin_amdgcn_s_barrier();                     // ... and everybody's; nobody still reads the buffers of chunk cc - 1
+        // waves w and w + 4 share a SIMD: the lower four issue the next chunk's burst before their MFMAs, the upper four
+        // after their first tap (see k_conv3_run)
+        const bool early = wv < 4;
+        if (early && cc + 1 < cpt) CHUNK_ISSUE(cc + 1);
+        const __half *ab = act0 + (size_t)(cc & 1) * apieces * 512;
+        const __half *wb = wt0 + (size_t)(cc & 1) * WPIECES * 512;
+        h8 bfx[2][FM], afx[2][FN];
+#define CHUNK_LOAD(S, T)                                                                                         \
+        do {                                                                                                     \
+            _Pragma("unroll") for (int j = 0; j < FM; ++j)                                                       \
+                bfx[S][j] = *reinterpret_cast<const h8 *>(ab + abase[T] + j * (16 * 32));                        \
+            _Pragma("unroll") for (int i = 0; i < FN; ++i)                                                       \
+                afx[S][i] = *reinterpret_cast<const h8 *>(wb + wlane + ((T) * BN + i * 16) * 32);                \
+        } while (0)
+#define CHUNK_MFMA(S, T)                                                                                         \
+        do {                                                                                                     \
+            _Pragma("unroll") for (int j = 0; j < FM; ++j)                                                       \
+                if (!((vm[j] >> (T)) & 1)) bfx[S][j] = hz;                                                       \
+            _Pragma("unroll") for (int i = 0; i < FN; ++i)                                                       \
+                _Pragma("unroll") for (int j = 0; j < FM; ++j)                                                   \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afx[S][i], bfx[S][j], acc[i][j], 0, 0, 0); \
+        } while (0)
+        CHUNK_LOAD(0, 0);
+        CHUNK_LOAD(1, 1);
+        CHUNK_MFMA(0, 0);
+        if (!early && cc + 1 < cpt) CHUNK_ISSUE(cc + 1);
+        CHUNK_LOAD(0, 2); CHUNK_MFMA(1, 1);
+        CHUNK_LOAD(1, 3); CHUNK_MFMA(0, 2);
+        CHUNK_LOAD(0, 4); CHUNK_MFMA(1, 3);
+        CHUNK_LOAD(1, 5); CHUNK_MFMA(0, 4);
+        CHUNK_LOAD(0, 6); CHUNK_MFMA(1, 5);
+        CHUNK_LOAD(1, 7); CHUNK_MFMA(0, 6);
+        CHUNK_LOAD(0, 8); CHUNK_MFMA(1, 7);
+        CHUNK_MFMA(0, 8);
+#undef CHUNK_LOAD
+#undef CHUNK_MFMA
+    }
+#undef CHUNK_ISSUE
+    __syncthreads();     // all waves done with the buffers: reuse them as the output staging tile
+
+    constexpr int SROW = BN + 8;
+    __half *stage = (__half *)smem;                       // [BM][SROW]
+#pragma unroll
+    for (int i = 0; i < FN; ++i) {
+        const int co = wn * TN + 16 * i + (lane >> 4) * 4;
+        const float4 bv = bvs[i];
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+            float v0 = acc[i][j][0] + bv.x, v1 = acc[i][j][1] + bv.y, v2 = acc[i][j][2] + bv.z, v3 = acc[i][j][3] + bv.w;
+            if (a.act) { v0 = silu_f(v0); v1 = silu_f(v1); v2 = silu_f(v2); v3 = silu_f(v3); }
+            const int px = wm * TM + 16 * j + (lane & 15);
+            __half2 lo = __floats2half2_rn(v0, v1), hi = __floats2half2_rn(v2, v3);
+            uint2 pk;
+            pk.x = *reinterpret_cast<uint32_t *>(&lo);
+            pk.y = *reinterpret_cast<uint32_t *>(&hi);
+            *reinterpret_cast<uint2 *>(stage + (size_t)px * SROW + co) = pk;
+        }
+    }
+    __syncthreads();
+    constexpr int CPR = BN / 8;
+#pragma unroll 4
+    for (int q = tid; q < BM * CPR; q += 512) {
+        const int row = q / CPR, pc = q - row * CPR;
+        const int co = n0 + pc * 8;
+        const int m = P0 + row;
+        if (m < a.M && co < a.Cout) {
+            uint4 v = *reinterpret_cast<const uint4 *>(stage + (size_t)row * SROW + pc * 8);
+            if (a.res) {
+                const uint4 r = *reinterpret_cast<const uint4 *>(a.res + (size_t)m * a.ldr + co);
+                __half2 *vh = reinterpret_cast<__half2 *>(&v);
+                const __half2 *rh = reinterpret_cast<const __half2 *>(&r);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float2 x = __half22float2(vh[u]), y = __half22float2(rh[u]);
+                    vh[u] = __floats2half2_rn(x.x + y.x, x.y + y.y);
+                }
+            }
+            *reinterpret_cast<uint4 *>(a.out + (size_t)m * a.ldo + co) = v;
+        }
+    }
+}
+
+template <int BM, int BN, int WGM, int WGN>
+hipError_t launch_chunk(RunArgs &a, hipStream_t s)
+{
+    if (a.Cin % 32 || a.CoutPad % 4 || a.W > 160) return hipErrorInvalidValue;
+    if ((size_t)a.M * a.ldi * 2 >= (1ull << 32) || (size_t)a.CoutPad * 9 * a.Cin * 2 >= (1ull << 32)) return hipErrorInvalidValue;
+    a.apieces = rva_ceil_div(BM + 2 * a.W + 2, 16);
+    if (a.apieces > 8 * 5) return hipErrorInvalidValue;   // MAXA pieces per wave
+    const size_t ring = (size_t)(2 * a.apieces + 2 * (9 * BN / 16)) * 1024;
+    const size_t st = (size_t)BM * (BN + 8) * 2;
+    const size_t smem = ring > st ? ring : st;
+    if (smem > 160 * 1024) return hipErrorInvalidValue;
+    if (hipError_t e = rva_func_smem((const void *)k_conv3_chunk<BM, BN, WGM, WGN>, 160 * 1024); e != hipSuccess) return e;
+    a.n_tiles = rva_ceil_div(a.Cout, BN);
+    a.m_tiles = rva_ceil_div(a.M, BM);
+    k_conv3_chunk<BM, BN, WGM, WGN><<<rva_ceil_div(a.m_tiles, 8) * 8 * a.n_tiles, 512, smem, s>>>(a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Large-tile LDS-DMA kernel for the gathered cases: 1x1 convolutions and 3x3 stride-2 (or stride-1) convolutions.
 // Same ring / counted-vmcnt / raw-barrier structure as k_conv3_big, but a K-step is (tap, 64 channels): every staged
 // row is one full 128-byte line of a pixel (or of a weight row), a 1 KiB piece is 8 rows, and the bank-conflict-free
@@ -2654,7 +2853,7 @@ __global__ void __launch_bounds__(1024) k_stem2(Stem2Args a)
 
 }  // namespace
 
-#define RVA_CONV_VARIANTS 66
+#define RVA_CONV_VARIANTS 73
 
 extern "C" {
 #ifdef RVA_ROW_STAMPS
@@ -2681,6 +2880,8 @@ int rva_dbg_read_stamps(unsigned long long *host) { return (int)hipMemcpyFromSym
 //   61..63 patch kernels for Cin = 64 with the output channels in two resident groups of 32
 //   64..65 LDS-DMA gather kernel with 256 x 256 tiles (64 MACs per staged byte; one block per CU): wave tile 64 x 128 / 128 x 64
 //   66     patch kernel with two wave sets half a tile period apart (3x3 stride 1, Cin = 64, Cout <= 64): 2 x 8 waves, one output row per wave
+//   67..73 "whole chunk per barrier" kernels for layers with few pixels (3x3 stride 1, Cin % 32 == 0): <BM,BN> = <128,64> <64,64>
+//          <256,64> <64,96> <128,96> <192,64> <256,96>; one barrier per 32-channel chunk (nine taps), one block per CU
 int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *weights, const float *bias, void *out,
                           int ldo, const void *residual, int ldr, int batch, int H, int W, int Cin, int Cout, int ksize,
                           int stride, int act, int variant, rva_stream_t stream_);
@@ -2733,6 +2934,27 @@ int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *wei
                                                  stride, act, pick, stream_);
             if (rc == RVA_OK) return rc;
         }
+    }
+    if (variant >= 67) {
+        // "whole chunk per barrier" kernels (3x3 stride 1, Cin % 32 == 0): the small-M layers, see k_conv3_chunk
+        hipError_t ev = hipErrorInvalidValue;
+        if (ksize == 3 && stride == 1) {
+            RunArgs g{};
+            g.in = a.in; g.ldi = ldi; g.w = a.w; g.bias = bias; g.out = a.out; g.ldo = ldo; g.res = a.res; g.ldr = ldr;
+            g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.CoutPad = rva_ceil_div(Cout, 64) * 64; g.act = act; g.M = a.M;
+            switch (variant) {
+            case 67: ev = launch_chunk<128, 64, 4, 2>(g, s); break;
+            case 68: ev = launch_chunk<64, 64, 2, 4>(g, s); break;
+            case 69: ev = launch_chunk<256, 64, 4, 2>(g, s); break;
+            case 70: ev = launch_chunk<64, 96, 4, 2>(g, s); break;
+            case 71: ev = launch_chunk<128, 96, 4, 2>(g, s); break;
+            case 72: ev = launch_chunk<192, 64, 4, 2>(g, s); break;
+            default: ev = launch_chunk<256, 96, 4, 2>(g, s); break;
+            }
+        }
+        if (ev == hipSuccess) return RVA_OK;
+        (void)hipGetLastError();
+        return rva_fail(ctx, ev == hipErrorInvalidValue ? RVA_ERR_ARG : RVA_ERR_HIP, "conv variant %d not applicable here", variant);
     }
     if (variant >= 66) {
         // patch kernel with two wave sets half a tile period apart (3x3 stride 1, Cin = 64, Cout <= 64)

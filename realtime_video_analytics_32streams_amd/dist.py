@@ -8,14 +8,57 @@ runs the same exclusive scan in canonical stream order inside ``k4_assign_ids``.
 (a few microseconds of payload), so it rides on the tick's stream right before id assignment.
 
 ``backend="nccl"`` is RCCL on ROCm; ``"gloo"`` is used by the CPU tests of this logic.
+
+Failure path.  The reference has one process, so its counter cannot lose a peer; here a dead rank must not leave the others
+blocked in the all-gather for ever (first contact with 8 real ranks must not be able to hang a node).  Three layers, all of
+them ending in a NON-ZERO EXIT of the surviving process (never a retry, never a re-exec of a process that has touched the GPU
+-- a supervisor restarts fresh children):
+  * the process group is created with a timeout (``RVA_DIST_TIMEOUT_S``, default 60 s): a host-blocking collective (gloo, the
+    rehearsal mode) raises when a peer is gone, and ``IdSync`` turns that into ``fail()``;
+  * RCCL collectives are enqueued on the tick's stream and never block the host, so ``PipelinedTicks`` waits for a sharded
+    tick with a deadline (``wait_event``: polls the tick's event) and calls ``fail()`` on expiry;
+  * torch's own NCCL watchdog (``TORCH_NCCL_ASYNC_ERROR_HANDLING``, on by default) aborts the process when a collective
+    exceeds the group timeout -- whichever fires first.
 """
 from __future__ import annotations
 
+import datetime
 import os
+import sys
+import time
 from typing import List, Optional, Sequence
 
 import torch
 import torch.distributed as dist
+
+EXIT_PEER_LOST = 13
+
+
+def timeout_s() -> float:
+    return float(os.environ.get("RVA_DIST_TIMEOUT_S", "60"))
+
+
+def fail(why: str) -> None:
+    """A peer is gone or a collective timed out: say so and leave with a non-zero status, at once.  ``os._exit``: no
+    atexit handlers, no destructor that could wait for the dead peer again (``destroy_process_group`` does)."""
+    rank = os.environ.get("RANK", "?")
+    print(f"[rva dist] rank {rank}: {why}; exiting with status {EXIT_PEER_LOST} (restart the job with fresh processes)",
+          file=sys.stderr, flush=True)
+    os._exit(EXIT_PEER_LOST)
+
+
+def wait_event(event, what: str = "tick", deadline_s: Optional[float] = None) -> None:
+    """Host wait for a HIP event of a sharded tick, bounded: a collective whose peer died never completes, and
+    ``event.synchronize()`` would then block for ever.  Polls; on expiry -> ``fail``."""
+    limit = time.monotonic() + (timeout_s() + 5.0 if deadline_s is None else deadline_s)
+    spins = 0
+    while not event.query():
+        spins += 1
+        if spins > 2000:                      # the common case (a tick takes milliseconds) never sleeps
+            time.sleep(2e-4)
+        if time.monotonic() > limit:
+            fail(f"{what} did not complete within {limit - time.monotonic() + (timeout_s() + 5.0 if deadline_s is None else deadline_s):.0f} s "
+                 "(a peer of the id exchange is gone or stuck)")
 
 
 def init_from_env(backend: Optional[str] = None) -> tuple[int, int, int]:
@@ -37,7 +80,8 @@ def init_from_env(backend: Optional[str] = None) -> tuple[int, int, int]:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=timeout_s()))
     return rank, world, local
 
 
@@ -81,12 +125,16 @@ class IdSync:
     def _gather(self, local_counts: torch.Tensor) -> torch.Tensor:
         if self.world == 1:
             self.buf.copy_(local_counts)
-        elif dist.get_backend(self.group) == "gloo" and self.buf.is_cuda:   # rehearsal mode: stage through the host
-            host = torch.zeros(self.buf.numel(), dtype=torch.int32)
-            dist.all_gather_into_tensor(host, local_counts.cpu().contiguous(), group=self.group)
-            self.buf.copy_(host)
-        else:
-            dist.all_gather_into_tensor(self.buf, local_counts.contiguous(), group=self.group)
+            return self.buf
+        try:
+            if self.backend == "gloo" and self.buf.is_cuda:        # rehearsal mode: stage through the host
+                host = torch.zeros(self.buf.numel(), dtype=torch.int32)
+                dist.all_gather_into_tensor(host, local_counts.cpu().contiguous(), group=self.group)
+                self.buf.copy_(host)
+            else:
+                dist.all_gather_into_tensor(self.buf, local_counts.contiguous(), group=self.group)
+        except Exception as exc:  # noqa: BLE001 -- a timed-out or broken collective (peer died, connection reset): no recovery here
+            fail(f"id exchange failed ({type(exc).__name__}: {str(exc).splitlines()[0][:200] if str(exc) else ''})")
         return self.buf
 
 

@@ -173,14 +173,22 @@ class SyntheticNv12Stream(_BaseStream):
     (seed = SEED_BASE + 1000 * stream_index, moving rectangles advance with the tick) and uploaded;
     the stream then cycles through them, so a steady-state run touches real, changing pixel data
     without paying host generation inside the timed region.
+
+    ``ring_frames`` > ``n_unique`` adds frames derived ON THE DEVICE from the generated ones (frame j = frame j mod
+    n_unique shifted horizontally by 16 * (j // n_unique) pixels, wrapping; valid NV12, own memory): a decoder hands the
+    pipeline new bytes every tick, and a ring whose frames of one tick (streams x 3.3 MB at 1080p) come round again only
+    after more than 2 x 256 MiB of other surfaces have been read cannot be served from the Infinity Cache.  ``bench.py``
+    sizes its rings that way; tests that compare against the oracle keep ``ring_frames`` unset (host-generated frames only).
     """
 
     def __init__(self, stream_config: StreamConfig, index: int = 0, width: int = 1920, height: int = 1080,
-                 pitch: Optional[int] = None, n_unique: int = 4, n_frames: Optional[int] = None, device="cuda"):
+                 pitch: Optional[int] = None, n_unique: int = 4, n_frames: Optional[int] = None, device="cuda",
+                 ring_frames: Optional[int] = None):
         super().__init__(stream_config)
         self.index, self.width, self.height = index, width, height
         self.pitch = pitch or ((width + 255) // 256) * 256
         self.n_unique, self.n_frames, self.device = n_unique, n_frames, device
+        self.ring_frames = max(int(ring_frames or n_unique), n_unique)
         self._ring = []
 
     def open_sync(self) -> None:
@@ -190,11 +198,17 @@ class SyntheticNv12Stream(_BaseStream):
             for t in range(self.n_unique):
                 y, uv = synth.make_nv12(seed, self.width, self.height, self.pitch, tick=t)
                 self._ring.append(Nv12Surface.from_numpy(y, uv, self.width, self.height, self.device))
+            for j in range(self.n_unique, self.ring_frames):
+                base, sh = self._ring[j % self.n_unique], 16 * (j // self.n_unique)
+                y, uv = base.y.clone(), base.uv.clone()
+                y[:, :self.width] = torch.roll(base.y[:, :self.width], sh, 1)
+                uv[:, :self.width] = torch.roll(base.uv[:, :self.width], sh, 1)      # interleaved UV: an even byte shift keeps U / V in place
+                self._ring.append(Nv12Surface(y, uv, self.width, self.height))
 
     def next_surface(self) -> Optional[Nv12Surface]:
         if self.n_frames is not None and self._frame_id >= self.n_frames:
             return None
-        return self._ring[self._frame_id % self.n_unique]
+        return self._ring[self._frame_id % len(self._ring)]
 
 
 def rocdecode_status() -> str:

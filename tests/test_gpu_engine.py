@@ -87,7 +87,9 @@ def test_conv_primitive_matches_fp32_reference(shape):
                                    (3, 17, 23, 64, 80, 3, 2), (2, 13, 11, 128, 80, 1, 1), (1, 5, 5, 64, 64, 3, 1),
                                    (5, 12, 10, 64, 192, 3, 1), (4, 80, 80, 64, 64, 3, 1), (2, 40, 40, 192, 128, 1, 1),
                                    # 32-channel-step LDS-DMA gather: the Cin = 32 / 96 layers
-                                   (2, 21, 18, 32, 64, 3, 2), (2, 16, 16, 96, 64, 1, 1), (1, 160, 160, 32, 64, 3, 2)])
+                                   (2, 21, 18, 32, 64, 3, 2), (2, 16, 16, 96, 64, 1, 1), (1, 160, 160, 32, 64, 3, 2),
+                                   # YOLOv8m widths at batch 4 (BASELINE configs[3] per GPU): the whole-chunk-per-barrier kernels, 96-channel tiles
+                                   (4, 40, 40, 192, 192, 3, 1), (4, 20, 20, 288, 288, 3, 1), (3, 23, 37, 96, 96, 3, 1)])
 def test_every_conv_variant_agrees(shape):
     """All kernel variants the autotuner may pick (gather / resident / row-reuse, every tile) give the same layer."""
     B, H, W, Cin, Cout, k, stride = shape
@@ -122,6 +124,9 @@ def test_every_conv_variant_agrees(shape):
         assert any(v >= 40 for v in ran), ran          # the 32-channel-step LDS-DMA gather kernel took part
         if k == 3 and stride == 1 and W <= 160:
             assert any(52 <= v <= 60 for v in ran), ran    # the long-run kernels took part
+            assert any(67 <= v <= 73 for v in ran), ran    # the whole-chunk-per-barrier kernels took part
+            if Cout % 96 == 0:
+                assert 70 in ran and 71 in ran, ran        # ... with 96-channel tiles
 
 
 def _stem_weights(w1, b1):
