@@ -259,6 +259,7 @@ def main():
     K = args.steps
     lat = np.empty(K)
     t_enq = np.empty(K)
+    t_sub = np.empty(K)                                   # host time inside submit(): what enqueueing one tick costs the CPU
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(K)]
     # dispatch-level event pair per tick for K1 (hipExtLaunchKernelGGL start/stop events, set through
     # rva_profile_next_preprocess): brackets exactly the kernel.  torch creates the hipEvent at the first record().
@@ -277,6 +278,7 @@ def main():
         if k % K1_SAMPLE_EVERY == 0:
             arm = lambda: N.lib().rva_profile_next_preprocess(rctx.handle, evk[k][0].cuda_event, evk[k][1].cuda_event)
         runner.submit(events=ev[k], before_k1=arm)
+        t_sub[k] = time.perf_counter() - t_enq[k]
 
     def finish(k):
         _, tables = runner.collect()
@@ -379,6 +381,8 @@ def main():
         "p99_latency_ms": round(float(np.percentile(lat, 99)) * 1e3, 3),
         "p50_latency_ms": round(float(np.percentile(lat, 50)) * 1e3, 3),
         "max_latency_ms": round(float(lat.max()) * 1e3, 3), "latency_samples": int(K),
+        "host_submit_us_per_tick": {"mean": round(float(t_sub.mean()) * 1e6, 1), "p50": round(float(np.percentile(t_sub, 50)) * 1e6, 1),
+                                    "what": "wall time inside PipelinedTicks.submit() on the host thread (every launch of the tick enqueued)"},
         "ticks_in_flight": runner.depth, "network_streams": runner.net_streams, "warmup_ticks_run": warm_ticks, "hip_graph": bool(use_graph), "hip_graph_scope": ("network + tail" if args.net_graph else ("post-process / tracker tail (networks launched eagerly; a tick is one chain on its own stream, consecutive ticks rotate over %d streams)" % runner.net_streams if runner.net_streams >= 2 else "post-process / tracker tail (network launched eagerly: concurrent detect branches)")) if use_graph else None, "realtime_32x30fps": bool(fps / world >= 30.0 * S and np.percentile(lat, 99) < 1 / 30),
         "stages_ms": {"k1_preprocess": round(float(k1_ms), 4), "detector": round(float(net_ms), 4),
                       "k2k3_postprocess": round(float(post_ms), 4), "k4_tracker": round(float(trk_ms), 4)},

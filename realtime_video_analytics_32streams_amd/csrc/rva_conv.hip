@@ -1404,7 +1404,9 @@ struct RunArgs {
     int H, W, Cin, Cout, CoutPad, act, n_tiles, M, m_tiles, apieces;
 };
 
-template <int BM, int BN, int WGM, int WGN>
+// NOSEL: timing-only experiment (private build, -DRVA_EXPERIMENTS: profiles/r04_experiments_not_kept.txt) -- the padding selects
+// compiled out, i.e. what a zero-halo activation layout could save at most; border pixels are then wrong.
+template <int BM, int BN, int WGM, int WGN, bool NOSEL = false>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BN <= 64 && BM <= 320 ? 4 : 2))) k_conv3_run(RunArgs a)
 {
     static_assert(WGM * WGN == 8, "eight waves");
@@ -1535,6 +1537,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BN <= 
         } while (0)
 #define RUN_MFMA(S, DX)                                                                                          \
         do {                                                                                                     \
+            if (!NOSEL)                                                                                          \
             _Pragma("unroll") for (int j = 0; j < FM; ++j)                                                       \
                 if (!((vm[j] >> (vsh + (DX))) & 1)) bfx[S][j] = hz;                                              \
             _Pragma("unroll") for (int i = 0; i < FN; ++i)                                                       \
@@ -1599,7 +1602,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BN <= 
     STAMP(6);
 }
 
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, bool NOSEL = false>
 hipError_t launch_run(RunArgs &a, hipStream_t s)
 {
     if (a.Cin % 32 || a.CoutPad % 4 || a.W > 160) return hipErrorInvalidValue;
@@ -1610,10 +1613,10 @@ hipError_t launch_run(RunArgs &a, hipStream_t s)
     const size_t st = (size_t)BM * (BN + 8) * 2;
     const size_t smem = ring > st ? ring : st;
     if (smem > 160 * 1024) return hipErrorInvalidValue;
-    if (hipError_t e = rva_func_smem((const void *)k_conv3_run<BM, BN, WGM, WGN>, 160 * 1024); e != hipSuccess) return e;
+    if (hipError_t e = rva_func_smem((const void *)k_conv3_run<BM, BN, WGM, WGN, NOSEL>, 160 * 1024); e != hipSuccess) return e;
     a.n_tiles = rva_ceil_div(a.Cout, BN);
     a.m_tiles = rva_ceil_div(a.M, BM);
-    k_conv3_run<BM, BN, WGM, WGN><<<rva_ceil_div(a.m_tiles, 8) * 8 * a.n_tiles, 512, smem, s>>>(a);
+    k_conv3_run<BM, BN, WGM, WGN, NOSEL><<<rva_ceil_div(a.m_tiles, 8) * 8 * a.n_tiles, 512, smem, s>>>(a);
     return hipGetLastError();
 }
 
@@ -1825,12 +1828,17 @@ hipError_t launch_chunk(RunArgs &a, hipStream_t s)
 // uses 64-byte rows with the swz32 rotation instead, 16 rows per piece.  Every wave owns BM/64 activation pieces
 // and BN/64 weight pieces per step, so the vmcnt count is a compile-time constant.  Taps that fall outside the image
 // read a clamped address and are zeroed per lane in the B fragment (9-bit mask per pixel).  Needs Cin % 64 == 0.
-template <int BM, int BN, int WGM, int WGN, int NSLOT, int KS, int BK, bool UP = false, bool HEAD = false>
+// SUB > 1 (round 4, two-slot rings only): SUB consecutive K-steps share ONE barrier -- the ring has NSLOT * SUB sub-slots, a
+// burst issues SUB steps, the MFMAs of SUB steps run between two barriers.  For the layers with few pixels (stride-2 and 1x1
+// layers at 20 x 20 / 40 x 40, batch 4: 13-78 workgroups walking 18-54 steps) the launch time is steps x step latency, and this
+// divides the steps; the LDS it costs (one workgroup per CU) is free where the grid is smaller than the chip.
+template <int BM, int BN, int WGM, int WGN, int NSLOT, int KS, int BK, bool UP = false, bool HEAD = false, int SUB = 1>
 __global__ void __launch_bounds__(512)
-    __attribute__((amdgpu_waves_per_eu(NSLOT * (BM + BN) * BK * 2 <= 80 * 1024 ? 4 : 2))) k_conv_gbig(ConvArgs a)
+    __attribute__((amdgpu_waves_per_eu(NSLOT * SUB * (BM + BN) * BK * 2 <= 80 * 1024 ? 4 : 2))) k_conv_gbig(ConvArgs a)
 {
     static_assert(WGM * WGN == 8, "eight waves");
     static_assert(BK == 32 || BK == 64, "K-step of 32 or 64 channels");
+    static_assert(SUB == 1 || NSLOT == 2, "several K-steps per barrier: two-slot ring");
     static_assert(!UP || (KS == 1 && BK == 64), "the upsample + concat source form exists for 1x1 convolutions");
     constexpr int TM = BM / WGM, TN = BN / WGN, FM = TM / 16, FN = TN / 16;
     constexpr int RPP = 512 / BK;                                  // rows per 1 KiB piece (8 rows of 128 B / 16 of 64 B)
@@ -1840,7 +1848,7 @@ __global__ void __launch_bounds__(512)
     constexpr int SLOTH = (BM + BN) * BK;                          // halfs per ring slot
     constexpr int TAPS = KS * KS, PAD = KS / 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __half *ring = (__half *)smem;                                 // [NSLOT][BM + BN][BK]
+    __half *ring = (__half *)smem;                                 // [NSLOT * SUB][BM + BN][BK]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1913,7 +1921,7 @@ __global__ void __launch_bounds__(512)
         ++is_cc;                                                                                                    \
         if (is_cc == cpt) { is_cc = 0; ++is_tap; }                                                                  \
         ++is_slot;                                                                                                  \
-        if (is_slot == NSLOT) is_slot = 0;                                                                          \
+        if (is_slot == NSLOT * SUB) is_slot = 0;                                                                    \
         is_cc = __builtin_amdgcn_readfirstlane(is_cc);                                                              \
         is_tap = __builtin_amdgcn_readfirstlane(is_tap);                                                            \
         is_slot = __builtin_amdgcn_readfirstlane(is_slot);                                                          \
@@ -1962,19 +1970,28 @@ __global__ void __launch_bounds__(512)
         bvs[i] = *reinterpret_cast<const float4 *>(a.bias + min(n0 + wn * TN + 16 * i + (lane >> 4) * 4, a.CoutPad - 4));
 
 #pragma unroll
-    for (int t = 0; t < NSLOT - 1; ++t)
+    for (int t = 0; t < (NSLOT - 1) * SUB; ++t)
         if (t < nsteps) GB_ISSUE();
     const int xr = lane & 7;                                       // BK 64: (row & 7) of every fragment row this lane reads
-    for (int s = 0; s < nsteps; ++s) {
+    const int nfat = (nsteps + SUB - 1) / SUB;                     // barriers: one per SUB K-steps
+    for (int sf = 0; sf < nfat; ++sf) {
         // steps s+1 .. s+NSLOT-2 may stay in flight (their pieces were issued after step s's)
-        wait_vm_n(NSLOT >= 3 ? min(max(nsteps - 1 - s, 0), NSLOT - 2) * my_pieces : 0);
+        wait_vm_n(NSLOT >= 3 ? min(max(nsteps - 1 - sf, 0), NSLOT - 2) * my_pieces : 0);
         __builtin_amdgcn_s_barrier();
-        const int sn = s + NSLOT - 1;
+        const int sn = (sf + NSLOT - 1) * SUB;                     // first K-step of the burst issued now
         const bool more = sn < nsteps;
         const bool early = NSLOT == 2 || wv < 4;
-        if (more && early) GB_ISSUE();
+        if (early) {
+#pragma unroll
+            for (int u = 0; u < SUB; ++u)
+                if (sn + u < nsteps) GB_ISSUE();
+        }
+#pragma unroll
+      for (int u = 0; u < SUB; ++u) {
+        const int s = sf * SUB + u;
+        if (SUB > 1 && s >= nsteps) break;
         const int tap = s / cpt;
-        const __half *ab = ring + (size_t)(s % NSLOT) * SLOTH;
+        const __half *ab = ring + (size_t)(s % (NSLOT * SUB)) * SLOTH;
         const __half *wb = ab + BM * BK;
         const int arow = wm * TM + (lane & 15), wr = wn * TN + (lane & 15);
 #pragma unroll
@@ -1994,7 +2011,8 @@ __global__ void __launch_bounds__(512)
                 for (int j = 0; j < FM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[j], acc[i][j], 0, 0, 0);
             }
         }
-        if (more && !early) GB_ISSUE();
+      }
+        if (more && !early) GB_ISSUE();                            // (three-slot rings: SUB == 1)
     }
 #undef GB_ISSUE
     __syncthreads();     // ring drained and no longer read: reuse it as the output staging tile
@@ -2091,29 +2109,30 @@ __global__ void __launch_bounds__(512)
     }
 }
 
-template <int BM, int BN, int WGM, int WGN, int NSLOT, int KS, int BK, bool UP = false, bool HEAD = false>
+template <int BM, int BN, int WGM, int WGN, int NSLOT, int KS, int BK, bool UP = false, bool HEAD = false, int SUB = 1>
 hipError_t launch_gbig1(ConvArgs &a, hipStream_t s)
 {
-    constexpr size_t ring = (size_t)NSLOT * (BM + BN) * BK * 2;
+    constexpr size_t ring = (size_t)NSLOT * SUB * (BM + BN) * BK * 2;
     constexpr size_t st = (size_t)BM * (BN + 8) * 2;
     constexpr size_t smem = ring > st ? ring : st;
     static_assert(smem <= 160 * 1024, "LDS budget");
-    if (hipError_t e = rva_func_smem((const void *)k_conv_gbig<BM, BN, WGM, WGN, NSLOT, KS, BK, UP, HEAD>, smem); e != hipSuccess) return e;
+    if (hipError_t e = rva_func_smem((const void *)k_conv_gbig<BM, BN, WGM, WGN, NSLOT, KS, BK, UP, HEAD, SUB>, smem); e != hipSuccess) return e;
     a.n_tiles = rva_ceil_div(a.Cout, BN);
     // LDS-DMA addresses are a 64-bit scalar base + a 32-bit per-lane byte offset
     if ((size_t)a.H * a.W * (size_t)(a.M / (a.Ho * a.Wo) + 1) * (UP ? a.ldi2 : a.ldi) * 2 >= (1ull << 32) ||
         (size_t)a.CoutPad * KS * KS * a.Cin * 2 >= (1ull << 32))
         return hipErrorInvalidValue;
     a.m_tiles = rva_ceil_div(a.M, BM);
-    k_conv_gbig<BM, BN, WGM, WGN, NSLOT, KS, BK, UP, HEAD><<<rva_ceil_div(a.m_tiles, 8) * 8 * a.n_tiles, 512, smem, s>>>(a);
+    k_conv_gbig<BM, BN, WGM, WGN, NSLOT, KS, BK, UP, HEAD, SUB><<<rva_ceil_div(a.m_tiles, 8) * 8 * a.n_tiles, 512, smem, s>>>(a);
     return hipGetLastError();
 }
 
-template <int BM, int BN, int WGM, int WGN, int NSLOT, int BK = 64>
+template <int BM, int BN, int WGM, int WGN, int NSLOT, int BK = 64, int SUB = 1>
 hipError_t launch_gbig(ConvArgs &a, int ksize, hipStream_t s)
 {
     if (a.Cin % BK || a.H > 2000 || a.W > 2000) return hipErrorInvalidValue;
-    return ksize == 1 ? launch_gbig1<BM, BN, WGM, WGN, NSLOT, 1, BK>(a, s) : launch_gbig1<BM, BN, WGM, WGN, NSLOT, 3, BK>(a, s);
+    return ksize == 1 ? launch_gbig1<BM, BN, WGM, WGN, NSLOT, 1, BK, false, false, SUB>(a, s)
+                      : launch_gbig1<BM, BN, WGM, WGN, NSLOT, 3, BK, false, false, SUB>(a, s);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2853,7 +2872,12 @@ __global__ void __launch_bounds__(1024) k_stem2(Stem2Args a)
 
 }  // namespace
 
-#define RVA_CONV_VARIANTS 73
+#define RVA_CONV_VARIANTS 79
+#ifdef RVA_EXPERIMENTS
+#define RVA_CONV_VARIANTS_MAX 99      // 90..: timing-only experiment kernels of a private build (tools/exp_build.py), never in librva.so
+#else
+#define RVA_CONV_VARIANTS_MAX RVA_CONV_VARIANTS
+#endif
 
 extern "C" {
 #ifdef RVA_ROW_STAMPS
@@ -2882,6 +2906,8 @@ int rva_dbg_read_stamps(unsigned long long *host) { return (int)hipMemcpyFromSym
 //   66     patch kernel with two wave sets half a tile period apart (3x3 stride 1, Cin = 64, Cout <= 64): 2 x 8 waves, one output row per wave
 //   67..73 "whole chunk per barrier" kernels for layers with few pixels (3x3 stride 1, Cin % 32 == 0): <BM,BN> = <128,64> <64,64>
 //          <256,64> <64,96> <128,96> <192,64> <256,96>; one barrier per 32-channel chunk (nine taps), one block per CU
+//   74..79 LDS-DMA gather kernel (as 33..39, two-slot ring) with SUB 64-channel K-steps per barrier: <BM,BN>xSUB = <128,128>x2 <128,64>x2
+//          <128,64>x3 <64,64>x4 <64,128>x3 <64,64>x2
 int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *weights, const float *bias, void *out,
                           int ldo, const void *residual, int ldr, int batch, int H, int W, int Cin, int Cout, int ksize,
                           int stride, int act, int variant, rva_stream_t stream_);
@@ -2901,7 +2927,7 @@ int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *wei
     if (!ctx) return RVA_ERR_ARG;
     hipStream_t s = (hipStream_t)stream_;
     if (!in || !weights || !bias || !out || batch <= 0 || H <= 0 || W <= 0 || (ksize != 1 && ksize != 3) ||
-        (stride != 1 && stride != 2) || Cin % 8 || Cout % 8 || ldi % 8 || ldo % 8 || (residual && ldr % 8) || variant < 0 || variant > RVA_CONV_VARIANTS ||
+        (stride != 1 && stride != 2) || Cin % 8 || Cout % 8 || ldi % 8 || ldo % 8 || (residual && ldr % 8) || variant < 0 || variant > RVA_CONV_VARIANTS_MAX ||
         ((uintptr_t)in | (uintptr_t)out | (uintptr_t)weights | (uintptr_t)residual) % 16)
         return rva_fail(ctx, RVA_ERR_ARG, "rva_conv2d_nhwc_f16: unsupported shape/alignment (Cin%%8, Cout%%8, ld%%8, 16-byte pointers)");
     ConvArgs a{};
@@ -2934,6 +2960,38 @@ int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *wei
                                                  stride, act, pick, stream_);
             if (rc == RVA_OK) return rc;
         }
+    }
+#ifdef RVA_EXPERIMENTS
+    if (variant >= 90) {
+        hipError_t ev = hipErrorInvalidValue;
+        if (ksize == 3 && stride == 1) {
+            RunArgs g{};
+            g.in = a.in; g.ldi = ldi; g.w = a.w; g.bias = bias; g.out = a.out; g.ldo = ldo; g.res = a.res; g.ldr = ldr;
+            g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.CoutPad = rva_ceil_div(Cout, 64) * 64; g.act = act; g.M = a.M;
+            if (variant == 90) ev = launch_run<256, 128, 4, 2, true>(g, s);       // run<256,128> without the padding selects
+            else if (variant == 91) ev = launch_run<256, 64, 4, 2, true>(g, s);   // run<256,64> without the padding selects
+        }
+        if (ev == hipSuccess) return RVA_OK;
+        (void)hipGetLastError();
+        return rva_fail(ctx, RVA_ERR_ARG, "experiment variant %d not applicable here", variant);
+    }
+#endif
+    if (variant >= 74) {
+        // LDS-DMA gather kernel with several 64-channel K-steps per barrier (1x1, 3x3 of either stride; Cin % 64 == 0): the small-M layers
+        a.CoutPad = cpad;
+        if (ksize == 1 && stride != 1) return rva_fail(ctx, RVA_ERR_ARG, "conv variant %d not applicable here", variant);
+        hipError_t ev;
+        switch (variant) {
+        case 74: ev = launch_gbig<128, 128, 2, 4, 2, 64, 2>(a, ksize, s); break;   // 128 KB
+        case 75: ev = launch_gbig<128, 64, 2, 4, 2, 64, 2>(a, ksize, s); break;    // 96 KB
+        case 76: ev = launch_gbig<128, 64, 2, 4, 2, 64, 3>(a, ksize, s); break;    // 144 KB
+        case 77: ev = launch_gbig<64, 64, 2, 4, 2, 64, 4>(a, ksize, s); break;     // 128 KB
+        case 78: ev = launch_gbig<64, 128, 2, 4, 2, 64, 3>(a, ksize, s); break;    // 144 KB
+        default: ev = launch_gbig<64, 64, 2, 4, 2, 64, 2>(a, ksize, s); break;     // 64 KB: two blocks per CU
+        }
+        if (ev == hipSuccess) return RVA_OK;
+        (void)hipGetLastError();
+        return rva_fail(ctx, ev == hipErrorInvalidValue ? RVA_ERR_ARG : RVA_ERR_HIP, "conv variant %d not applicable here", variant);
     }
     if (variant >= 67) {
         // "whole chunk per barrier" kernels (3x3 stride 1, Cin % 32 == 0): the small-M layers, see k_conv3_chunk

@@ -139,12 +139,18 @@ class HipYoloDetector(BaseDetector):
                                         dtype=torch.float16 if self.half else torch.float32))
 
     # -- stages ---------------------------------------------------------------------------------
+    def input_tensor(self, batch: int) -> torch.Tensor:
+        """The input tensor K1 writes for this batch size and the current slot (cached for the life of the detector)."""
+        n = batch if self._slot == 0 else (batch, self._slot)                  # buffer key: batch size (, slot)
+        t = self._in_bufs.get(n)
+        if t is None:
+            dt = torch.float16 if self.half else torch.float32
+            t = self._in_bufs[n] = torch.empty((batch, 3, *self.input_hw), dtype=dt, device=self.device)
+        return t
+
     def _preprocess(self, frames: Sequence) -> tuple[torch.Tensor, N.Letterbox]:
         n = len(frames) if self._slot == 0 else (len(frames), self._slot)      # buffer key: batch size (, slot)
-        dt = torch.float16 if self.half else torch.float32
-        self._in = self._in_bufs.get(n)
-        if self._in is None:
-            self._in = self._in_bufs[n] = torch.empty((len(frames), 3, *self.input_hw), dtype=dt, device=self.device)
+        self._in = self.input_tensor(len(frames))
         f0 = frames[0]
         if isinstance(f0, ops.Nv12Surface):
             # the border (pad value) of the input tensor is constant per geometry: the first launch into a buffer writes it,

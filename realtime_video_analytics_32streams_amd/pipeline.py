@@ -432,10 +432,10 @@ class PipelinedTicks:
         # rings), and its network for the tick two before it to have released the head tensors of its parity.
         import os
         net_streams = int(os.environ.get("RVA_NET_STREAMS", net_streams))      # A/B switch for measurements
-        self.net_streams = depth if (net_streams >= 2 and self.two_streams and depth >= 2 and not self.net_graph) else 1
+        self.net_streams = depth if (net_streams >= 2 and self.two_streams and depth >= 2) else 1
         if depth > 2 and self.net_streams == 1:
-            # more than two ticks in flight need one chain per tick (fused or two_chain_ok detectors, no net_graph, RVA_NET_STREAMS
-            # unset); the one-network-stream layout has two head tensors per plan: two ticks in flight
+            # more than two ticks in flight need one chain per tick (fused or two_chain_ok detectors, RVA_NET_STREAMS unset);
+            # the one-network-stream layout has two head tensors per plan: two ticks in flight
             self.depth = depth = 2
             self.nslots = 2
         # Two explicit streams created back to back (the runtime spreads consecutive streams over its hardware queues; the
@@ -516,14 +516,19 @@ class PipelinedTicks:
             pair = []
             for par in range(self.nslots):
                 self._set_slot(par)
-                fp = self._plan_of(det, pres[gi][0])
+                # the slot's own input tensor (tick chains: one per slot; it exists once the slot has run, else it is made here)
+                pre_par = pres[gi]
+                if self.net_streams >= 2 and self.net_graph:
+                    with torch.inference_mode():
+                        pre_par = (det.input_tensor(int(pres[gi][0].shape[0])),) + tuple(pres[gi][1:])
+                fp = self._plan_of(det, pre_par[0])
                 # head tensor (group, parity): a stable buffer of the plan (two network streams: of the parity's own plan)
                 raws[gi][par] = fp.use_output(gi if self.net_streams >= 2 else 2 * gi + par)
                 if self.net_graph:
                     gr = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(gr):
                         with torch.inference_mode():
-                            det.stage_net(pres[gi])                # network only, writes that head tensor
+                            det.stage_net(pre_par)                 # network only, writes that head tensor
                     pair.append(gr)
             self._net_graphs.append(pair)
         torch.cuda.synchronize()

@@ -122,6 +122,8 @@ def test_every_conv_variant_agrees(shape):
             assert any(21 <= v <= 32 for v in ran), ran      # the large-tile LDS-DMA kernel took part
     if Cin % 32 == 0:
         assert any(v >= 40 for v in ran), ran          # the 32-channel-step LDS-DMA gather kernel took part
+    if Cin % 64 == 0 and (k == 3 or stride == 1):
+        assert all(v in ran for v in range(74, 80)), ran   # the gather kernels with several K-steps per barrier took part
         if k == 3 and stride == 1 and W <= 160:
             assert any(52 <= v <= 60 for v in ran), ran    # the long-run kernels took part
             assert any(67 <= v <= 73 for v in ran), ran    # the whole-chunk-per-barrier kernels took part
