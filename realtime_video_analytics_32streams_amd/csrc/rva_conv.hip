@@ -89,6 +89,20 @@ constexpr int LDSROW = 40;  // halfs per staged row, padded layout (stem, reside
 // and the staging ds_write_b128 (4 lanes per row, consecutive rows) alternates 16-bank halves: both conflict-free.
 __device__ __forceinline__ int swz32(int row, int chunk) { return row * 32 + (((chunk + 2 * (row >> 2)) & 3) << 3); }
 
+// q / d for 0 <= q < 2^24 and d > 0, with inv = 1.0f / d: a float multiply and a one-step correction (~8 instructions) instead
+// of the ~40-instruction 32-bit division.  The LDS-DMA kernels turn raster positions into image coordinates once per lane
+// before their main loop, and that start-up arithmetic is not free: with the per-fragment tap masks compiled out (and with
+// them their divisions) the 3x3 kernels ran 12-20 % faster (profiles/r04_experiments_not_kept.txt #2) -- the masks are now
+// computed with div_s, AFTER the first LDS-DMA burst has been issued, under its latency.
+__device__ __forceinline__ int div_s(int q, int d, float inv)
+{
+    int t = (int)((float)q * inv);
+    const int r = q - t * d;
+    if (r < 0) --t;
+    if (r >= d) ++t;
+    return t;
+}
+
 // x * sigmoid(x) with v_exp_f32 + v_rcp_f32 (1 ulp): __fdividef / operator/ expand to the ~12-instruction IEEE
 // division sequence here, which dominated the epilogues (64-128 SiLUs per thread per tile)
 __device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
@@ -1100,6 +1114,19 @@ __device__ __forceinline__ void lds_dma16(unsigned voff, const void *sbase, unsi
     const unsigned m0s = __builtin_amdgcn_readfirstlane(m0v);
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sb), "s"(m0s) : "memory");
 }
+// The same piece with only the lanes of `mask` active: the other lanes neither load nor write their 16 bytes of LDS (what
+// k_conv3_run<..., PADO> needs for the pad positions of its padded raster, which are zeroed once and must stay zero).  Only
+// from wave-uniform control flow with all 64 lanes active (every issue site of these kernels): EXEC is restored to all ones.
+__device__ __forceinline__ void lds_dma16_masked(unsigned voff, const void *sbase, unsigned m0v, unsigned long long mask)
+{
+    const unsigned long long b = (unsigned long long)(size_t)sbase;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    const unsigned long long sb = ((unsigned long long)hi << 32) | lo;
+    const unsigned m0s = __builtin_amdgcn_readfirstlane(m0v);
+    const unsigned mlo = __builtin_amdgcn_readfirstlane((unsigned)mask), mhi = __builtin_amdgcn_readfirstlane((unsigned)(mask >> 32));
+    const unsigned long long ms = ((unsigned long long)mhi << 32) | mlo;
+    asm volatile("s_mov_b32 m0, %2\n\ts_mov_b64 exec, %3\n\tglobal_load_lds_dwordx4 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(voff), "s"(sb), "s"(m0s), "s"(ms) : "memory");
+}
 __device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(size_t)(lds_vptr)p; }
 __device__ __forceinline__ void wait_vm_n(int n)
 {
@@ -1213,19 +1240,6 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NSLOT 
         BIG_ISSUE_ADVANCE();                                                                                  \
     } while (0)
 
-    // 9-bit tap validity per pixel fragment: bit dy*3+dx set when tap (dy,dx) of that pixel lies inside its image
-    int vm[FM];
-#pragma unroll
-    for (int j = 0; j < FM; ++j) {
-        const int p = P0 + wm * TM + 16 * j + (lane & 15);
-        int m = 0;
-        if (p < a.M) {
-            const int rem = p % HW, oy = rem / a.W, ox = rem - oy * a.W;
-            const int hv = (ox >= 1 ? 1 : 0) | 2 | (ox <= a.W - 2 ? 4 : 0);
-            m = (oy >= 1 ? hv : 0) | (hv << 3) | (oy <= a.H - 2 ? hv << 6 : 0);
-        }
-        vm[j] = m;
-    }
 
     f4 acc[FN][FM];
 #pragma unroll
@@ -1250,6 +1264,23 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NSLOT 
 #pragma unroll
     for (int t = 0; t < NSLOT - 1; ++t)
         if (t < nsteps) BIG_ISSUE();
+    // 9-bit tap validity per pixel fragment: bit dy*3+dx set when tap (dy,dx) of that pixel lies inside its image (computed
+    // here, under the latency of the first burst: see div_s)
+    int vm[FM];
+    {
+        const float inv_hw = 1.0f / (float)HW, inv_w = 1.0f / (float)a.W;
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+            const int p = P0 + wm * TM + 16 * j + (lane & 15);
+            int m = 0;
+            if (p < a.M) {
+                const int rem = p - div_s(p, HW, inv_hw) * HW, oy = div_s(rem, a.W, inv_w), ox = rem - oy * a.W;
+                const int hv = (ox >= 1 ? 1 : 0) | 2 | (ox <= a.W - 2 ? 4 : 0);
+                m = (oy >= 1 ? hv : 0) | (hv << 3) | (oy <= a.H - 2 ? hv << 6 : 0);
+            }
+            vm[j] = m;
+        }
+    }
     STAMP(1);
     for (int s = 0; s < nsteps; ++s) {
         // retire this wave's pieces of step s (with three slots those of step s+1 stay in flight), then meet the
@@ -1374,7 +1405,7 @@ hipError_t launch_big(BigArgs &a, hipStream_t s)
     constexpr size_t st = (size_t)BM * (BN + 8) * 2;
     constexpr size_t smem = ring > st ? ring : st;
     static_assert(smem <= 160 * 1024, "LDS budget");
-    if (a.Cin % 32 || a.CoutPad % 4) return hipErrorInvalidValue;
+    if (a.Cin % 32 || a.CoutPad % 4 || a.M >= (1 << 24)) return hipErrorInvalidValue;     // (div_s: raster positions below 2^24)
     // LDS-DMA addresses are a 64-bit scalar base + a 32-bit per-lane byte offset
     if ((size_t)a.M * a.ldi * 2 >= (1ull << 32) || (size_t)a.CoutPad * 9 * a.Cin * 2 >= (1ull << 32)) return hipErrorInvalidValue;
     if (hipError_t e = rva_func_smem((const void *)k_conv3_big<BM, BN, WGM, WGN, NSLOT>, smem); e != hipSuccess) return e;
@@ -1401,12 +1432,22 @@ struct RunArgs {
     const __half *w; const float *bias;
     __half *out; int ldo;
     const __half *res; int ldr;
-    int H, W, Cin, Cout, CoutPad, act, n_tiles, M, m_tiles, apieces;
+    int H, W, Cin, Cout, CoutPad, act, n_tiles, M, m_tiles, apieces, map_off;
 };
 
 // NOSEL: timing-only experiment (private build, -DRVA_EXPERIMENTS: profiles/r04_experiments_not_kept.txt) -- the padding selects
 // compiled out, i.e. what a zero-halo activation layout could save at most; border pixels are then wrong.
-template <int BM, int BN, int WGM, int WGN, bool NOSEL = false>
+//
+// PADO (round 4): the padding selects leave the MFMA phase by making the tile a run of PADDED positions.  The raster the
+// kernel walks has row pitch W + 1 (one pad position after every image row: right pad of row y, left pad of row y + 1) and one
+// pad row after every image; a tile is BM consecutive positions of it, the LDS run holds positions [P0 - (W+1) - 1,
+// P0 + BM + (W+1) + 1), and every tap of every position is the position at a FIXED offset -- a real pixel or a pad position
+// that holds zeros.  The tensor in HBM keeps its layout: the lanes of an LDS-DMA piece whose run rows are real pixels fetch
+// those pixels, the lanes whose rows are pad positions are masked out of the piece (EXEC) and their 16 bytes, zeroed once
+// before the first step, are never written again.  The price: the MFMAs also run for the pad positions among the tile's
+// outputs (1 / W + 1 / H of the work: 5 % at 40 x 40, 2.5 % at 80 x 80, 10 % at 20 x 20), whose rows the epilogue skips (a
+// per-row pixel index in LDS).
+template <int BM, int BN, int WGM, int WGN, bool NOSEL = false, bool PADO = false>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BN <= 64 && BM <= 320 ? 4 : 2))) k_conv3_run(RunArgs a)
 {
     static_assert(WGM * WGN == 8, "eight waves");
@@ -1432,30 +1473,41 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BN <= 
 
     const int lrow = lane >> 2, lp = lane & 3;
     unsigned aoff[MAXA], woff[NPW];
+    const int Wp = PADO ? a.W + 1 : a.W, HWp = (a.H + 1) * Wp;      // PADO: pitch of the padded raster
+    const float inv_wp = 1.0f / (float)Wp, inv_hwp = 1.0f / (float)HWp;
+    unsigned long long amask[PADO ? MAXA : 1];            // PADO: the lanes of piece wv + 8k whose run row is a real pixel
+    // PADO: position -> pixel index (or -1 for a pad position / past the tensor)
+    auto pixel_of = [&](int pos) {
+        if (pos < 0) return -1;
+        const int b = div_s(pos, HWp, inv_hwp), rem = pos - b * HWp, yy = div_s(rem, Wp, inv_wp), xx = rem - yy * Wp;
+        const int m = (b * a.H + yy) * a.W + xx;
+        return (yy < a.H && xx < a.W && m < a.M) ? m : -1;
+    };
 #pragma unroll
     for (int k = 0; k < MAXA; ++k) {
         const int r = (wv + 8 * k) * 16 + lrow;           // row of the run
-        const int q = min(max(P0 - a.W - 1 + r, 0), a.M - 1);
+        int q;
+        if (PADO) {
+            q = pixel_of(P0 - Wp - 1 + r);
+            amask[k] = __builtin_amdgcn_ballot_w64(q >= 0);
+            if (q < 0) q = 0;
+        } else {
+            q = min(max(P0 - a.W - 1 + r, 0), a.M - 1);
+        }
         aoff[k] = (unsigned)q * (unsigned)(a.ldi * 2) + (unsigned)(((lp - 2 * (r >> 2)) & 3) * 16);
+    }
+    int *rowmap = (int *)(smem + a.map_off);              // PADO: pixel index of every output row of the tile, -1 = skip
+    if (PADO) {
+        for (int r = tid; r < BM; r += 512) rowmap[r] = pixel_of(P0 + r);
+        // both run buffers start as zeros: the masked pieces never write the pad positions
+        for (int i = tid; i < 2 * apieces * 64; i += 512) reinterpret_cast<uint4 *>(smem)[i] = uint4{0u, 0u, 0u, 0u};
+        __syncthreads();
     }
 #pragma unroll
     for (int k = 0; k < NPW; ++k) {
         const int rw = (wv + 8 * k) * 16 + lrow;
         const int dx = rw / BN, co = min(n0 + rw - dx * BN, a.CoutPad - 1);
         woff[k] = (unsigned)(co * wrow + min(dx, 2) * a.Cin) * 2u + (unsigned)(((lp - 2 * (rw >> 2)) & 3) * 16);
-    }
-    // 9-bit tap validity per pixel fragment
-    int vm[FM];
-#pragma unroll
-    for (int j = 0; j < FM; ++j) {
-        const int p = P0 + wm * TM + 16 * j + (lane & 15);
-        int m = 0;
-        if (p < a.M) {
-            const int rem = p % HW, oy = rem / a.W, ox = rem - oy * a.W;
-            const int hv = (ox >= 1 ? 1 : 0) | 2 | (ox <= a.W - 2 ? 4 : 0);
-            m = (oy >= 1 ? hv : 0) | (hv << 3) | (oy <= a.H - 2 ? hv << 6 : 0);
-        }
-        vm[j] = m;
     }
     f4 acc[FN][FM];
 #pragma unroll
@@ -1478,11 +1530,30 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BN <= 
     // prologue: the whole run of chunk 0 and the weights of step 0
 #pragma unroll
     for (int k = 0; k < MAXA; ++k)
-        if (wv + 8 * k < apieces) lds_dma16(aoff[k], a.in, lds_act + (unsigned)(wv + 8 * k) * 1024u);
+        if (wv + 8 * k < apieces) {
+            if (PADO) lds_dma16_masked(aoff[k], a.in, lds_act + (unsigned)(wv + 8 * k) * 1024u, amask[PADO ? k : 0]);
+            else lds_dma16(aoff[k], a.in, lds_act + (unsigned)(wv + 8 * k) * 1024u);
+        }
 #pragma unroll
     for (int k = 0; k < NPW; ++k)
         if (wv + 8 * k < WPIECES) lds_dma16(woff[k], a.w, lds_w + (unsigned)(wv + 8 * k) * 1024u);
     const int wlane = swz32(wn * TN + (lane & 15), lane >> 4);      // this lane's weight row of fragment 0, tap 0
+    // 9-bit tap validity per pixel fragment (under the latency of the prologue burst: see div_s)
+    int vm[FM];
+    {
+        const float inv_hw = 1.0f / (float)HW, inv_w = 1.0f / (float)a.W;
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+            const int p = P0 + wm * TM + 16 * j + (lane & 15);
+            int m = 0;
+            if (!PADO && p < a.M) {
+                const int rem = p - div_s(p, HW, inv_hw) * HW, oy = div_s(rem, a.W, inv_w), ox = rem - oy * a.W;
+                const int hv = (ox >= 1 ? 1 : 0) | 2 | (ox <= a.W - 2 ? 4 : 0);
+                m = (oy >= 1 ? hv : 0) | (hv << 3) | (oy <= a.H - 2 ? hv << 6 : 0);
+            }
+            vm[j] = m;
+        }
+    }
 
     int cc = 0, dy = 0;
     STAMP(1);
@@ -1511,7 +1582,10 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BN <= 
                 const char *ab_ = (const char *)a.in + (cc + 1) * 64;                                            \
                 const unsigned l_ = lds_act + (unsigned)((cc + 1) & 1) * (unsigned)(apieces * 1024);             \
                 _Pragma("unroll") for (int k = 0; k < MAXA; ++k)                                                 \
-                    if (k % 3 == dy && wv + 8 * k < apieces) lds_dma16(aoff[k], ab_, l_ + (unsigned)(wv + 8 * k) * 1024u); \
+                    if (k % 3 == dy && wv + 8 * k < apieces) {                                                   \
+                        if (PADO) lds_dma16_masked(aoff[k], ab_, l_ + (unsigned)(wv + 8 * k) * 1024u, amask[PADO ? k : 0]); \
+                        else lds_dma16(aoff[k], ab_, l_ + (unsigned)(wv + 8 * k) * 1024u);                       \
+                    }                                                                                            \
             }                                                                                                    \
         } while (0)
         const bool early = wv < 4;
@@ -1522,7 +1596,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BN <= 
         // Fragment addresses = one swizzled per-lane base per horizontal tap + instruction immediates (16 rows further the
         // rotation of swz32 is the same; weight rows are the lane's base + a multiple of 16 rows): the PMC pass showed 4.4 vector
         // instructions per MFMA in this kernel, and every one of them competes with the MFMAs for the SIMD's issue port.
-        const int arow = wm * TM + (lane & 15) + dy * a.W, ch = lane >> 4;
+        const int arow = wm * TM + (lane & 15) + dy * Wp, ch = lane >> 4;
         const int abase[3] = {swz32(arow, ch), swz32(arow + 1, ch), swz32(arow + 2, ch)};
         const int vsh = dy * 3;
         // the fragments of the next horizontal tap are read while the MFMAs of this one run (two register sets); the padding
@@ -1537,7 +1611,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BN <= 
         } while (0)
 #define RUN_MFMA(S, DX)                                                                                          \
         do {                                                                                                     \
-            if (!NOSEL)                                                                                          \
+            if (!NOSEL && !PADO)                                                                                 \
             _Pragma("unroll") for (int j = 0; j < FM; ++j)                                                       \
                 if (!((vm[j] >> (vsh + (DX))) & 1)) bfx[S][j] = hz;                                              \
             _Pragma("unroll") for (int i = 0; i < FN; ++i)                                                       \
@@ -1583,8 +1657,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BN <= 
     for (int q = tid; q < BM * CPR; q += 512) {
         const int row = q / CPR, pc = q - row * CPR;
         const int co = n0 + pc * 8;
-        const int m = P0 + row;
-        if (m < a.M && co < a.Cout) {
+        const int m = PADO ? rowmap[row] : P0 + row;
+        if ((PADO ? m >= 0 : m < a.M) && co < a.Cout) {
             uint4 v = *reinterpret_cast<const uint4 *>(stage + (size_t)row * SROW + pc * 8);
             if (a.res) {
                 const uint4 r = *reinterpret_cast<const uint4 *>(a.res + (size_t)m * a.ldr + co);
@@ -1602,21 +1676,30 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BN <= 
     STAMP(6);
 }
 
-template <int BM, int BN, int WGM, int WGN, bool NOSEL = false>
+template <int BM, int BN, int WGM, int WGN, bool NOSEL = false, bool PADO = false>
 hipError_t launch_run(RunArgs &a, hipStream_t s)
 {
-    if (a.Cin % 32 || a.CoutPad % 4 || a.W > 160) return hipErrorInvalidValue;
+    if (a.Cin % 32 || a.CoutPad % 4 || a.W > 160 || a.M >= (1 << 24)) return hipErrorInvalidValue;
     if ((size_t)a.M * a.ldi * 2 >= (1ull << 32) || (size_t)a.CoutPad * 9 * a.Cin * 2 >= (1ull << 32)) return hipErrorInvalidValue;
-    a.apieces = rva_ceil_div(BM + 2 * a.W + 2, 16);
+    const int wp = PADO ? a.W + 1 : a.W;
+    a.apieces = rva_ceil_div(BM + 2 * wp + 2, 16);
     if (a.apieces > 8 * 5) return hipErrorInvalidValue;   // MAXA pieces per wave
     const size_t ring = (size_t)(2 * a.apieces + 2 * (3 * BN / 16)) * 1024;
     const size_t st = (size_t)BM * (BN + 8) * 2;
-    const size_t smem = ring > st ? ring : st;
+    size_t smem = ring > st ? ring : st;
+    long mp = a.M;
+    if (PADO) {
+        const int batch = a.M / (a.H * a.W);
+        mp = (long)batch * (a.H + 1) * (a.W + 1);         // positions of the padded raster (div_s: below 2^24)
+        if (a.M % (a.H * a.W) || mp >= (1l << 24)) return hipErrorInvalidValue;
+        a.map_off = (int)smem;                            // per-row pixel index behind the rings / the output stage
+        smem += (size_t)BM * 4;
+    }
     if (smem > 160 * 1024) return hipErrorInvalidValue;
-    if (hipError_t e = rva_func_smem((const void *)k_conv3_run<BM, BN, WGM, WGN, NOSEL>, 160 * 1024); e != hipSuccess) return e;
+    if (hipError_t e = rva_func_smem((const void *)k_conv3_run<BM, BN, WGM, WGN, NOSEL, PADO>, 160 * 1024); e != hipSuccess) return e;
     a.n_tiles = rva_ceil_div(a.Cout, BN);
-    a.m_tiles = rva_ceil_div(a.M, BM);
-    k_conv3_run<BM, BN, WGM, WGN, NOSEL><<<rva_ceil_div(a.m_tiles, 8) * 8 * a.n_tiles, 512, smem, s>>>(a);
+    a.m_tiles = (int)((mp + BM - 1) / BM);
+    k_conv3_run<BM, BN, WGM, WGN, NOSEL, PADO><<<rva_ceil_div(a.m_tiles, 8) * 8 * a.n_tiles, 512, smem, s>>>(a);
     return hipGetLastError();
 }
 
@@ -1673,18 +1756,6 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) k
         const int tap = min(rw / BN, 8), co = min(n0 + rw - tap * BN, a.CoutPad - 1);
         woff[k] = (unsigned)(co * wrow + tap * a.Cin) * 2u + (unsigned)(((lp - 2 * (rw >> 2)) & 3) * 16);
     }
-    int vm[FM];                                           // 9-bit tap validity per pixel fragment
-#pragma unroll
-    for (int j = 0; j < FM; ++j) {
-        const int p = P0 + wm * TM + 16 * j + (lane & 15);
-        int m = 0;
-        if (p < a.M) {
-            const int rem = p % HW, oy = rem / a.W, ox = rem - oy * a.W;
-            const int hv = (ox >= 1 ? 1 : 0) | 2 | (ox <= a.W - 2 ? 4 : 0);
-            m = (oy >= 1 ? hv : 0) | (hv << 3) | (oy <= a.H - 2 ? hv << 6 : 0);
-        }
-        vm[j] = m;
-    }
     f4 acc[FN][FM];
 #pragma unroll
     for (int i = 0; i < FN; ++i)
@@ -1708,6 +1779,22 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) k
             if (wv + 8 * k < apieces) lds_dma16(aoff[k], ab_, la_ + (unsigned)(wv + 8 * k) * 1024u);             \
     } while (0)
     CHUNK_ISSUE(0);
+    // 9-bit tap validity per pixel fragment (under the latency of the first burst: see div_s)
+    int vm[FM];
+    {
+        const float inv_hw = 1.0f / (float)HW, inv_w = 1.0f / (float)a.W;
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+            const int p = P0 + wm * TM + 16 * j + (lane & 15);
+            int m = 0;
+            if (p < a.M) {
+                const int rem = p - div_s(p, HW, inv_hw) * HW, oy = div_s(rem, a.W, inv_w), ox = rem - oy * a.W;
+                const int hv = (ox >= 1 ? 1 : 0) | 2 | (ox <= a.W - 2 ? 4 : 0);
+                m = (oy >= 1 ? hv : 0) | (hv << 3) | (oy <= a.H - 2 ? hv << 6 : 0);
+            }
+            vm[j] = m;
+        }
+    }
     // per-lane fragment bases, fixed for the whole kernel: the run row of the lane's first pixel for each of the nine taps
     // (swizzled; 16 rows further the rotation repeats, so the other fragments are immediates) and its first weight row
     const int ch = lane >> 4;
@@ -1804,7 +1891,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) k
 template <int BM, int BN, int WGM, int WGN>
 hipError_t launch_chunk(RunArgs &a, hipStream_t s)
 {
-    if (a.Cin % 32 || a.CoutPad % 4 || a.W > 160) return hipErrorInvalidValue;
+    if (a.Cin % 32 || a.CoutPad % 4 || a.W > 160 || a.M >= (1 << 24)) return hipErrorInvalidValue;
     if ((size_t)a.M * a.ldi * 2 >= (1ull << 32) || (size_t)a.CoutPad * 9 * a.Cin * 2 >= (1ull << 32)) return hipErrorInvalidValue;
     a.apieces = rva_ceil_div(BM + 2 * a.W + 2, 16);
     if (a.apieces > 8 * 5) return hipErrorInvalidValue;   // MAXA pieces per wave
@@ -1873,6 +1960,7 @@ __global__ void __launch_bounds__(512)
     // sits in the scalar base.  UP: two sources, one offset each (low-res pixel / full-res pixel).
     unsigned actr[NA], actr2[UP ? NA : 1];
     int avm[NA];
+    const float inv_howo = 1.0f / (float)HoWo, inv_wo = 1.0f / (float)a.Wo;      // div_s: raster positions below 2^24 (launch_gbig1)
 #pragma unroll
     for (int k = 0; k < NA; ++k) {
         const int m = P0 + (wv + 8 * k) * RPP + lrow;
@@ -1880,16 +1968,16 @@ __global__ void __launch_bounds__(512)
         avm[k] = 0;
         if (UP) actr2[k] = (unsigned)(c8 * 2);
         if (wv + 8 * k < APIECES && m < a.M) {
-            const int b = m / HoWo, rem = m - b * HoWo, oy = rem / a.Wo, ox = rem - oy * a.Wo;
+            const int b = div_s(m, HoWo, inv_howo), rem = m - b * HoWo, oy = div_s(rem, a.Wo, inv_wo), ox = rem - oy * a.Wo;
             const int iy0 = oy * a.stride - PAD, ix0 = ox * a.stride - PAD;
             const unsigned pix = (unsigned)((b * a.H + iy0 + PAD) * a.W + ix0 + PAD);
             actr[k] = pix * (unsigned)((UP ? a.ldi2 : a.ldi) * 2) + (unsigned)(c8 * 2);
             if (UP) actr2[k] = (unsigned)((b * (a.H >> 1) + (oy >> 1)) * (a.W >> 1) + (ox >> 1)) * (unsigned)(a.ldi * 2) + (unsigned)(c8 * 2);
             int msk = KS == 1 ? 1 : 0;
             if (KS == 3) {
-#pragma unroll
-                for (int t = 0; t < 9; ++t)
-                    if ((unsigned)(iy0 + t / 3) < (unsigned)a.H && (unsigned)(ix0 + t % 3) < (unsigned)a.W) msk |= 1 << t;
+                const int vy = ((unsigned)iy0 < (unsigned)a.H ? 1 : 0) | ((unsigned)(iy0 + 1) < (unsigned)a.H ? 2 : 0) | ((unsigned)(iy0 + 2) < (unsigned)a.H ? 4 : 0);
+                const int vx = ((unsigned)ix0 < (unsigned)a.W ? 1 : 0) | ((unsigned)(ix0 + 1) < (unsigned)a.W ? 2 : 0) | ((unsigned)(ix0 + 2) < (unsigned)a.W ? 4 : 0);
+                msk = ((vy & 1) ? vx : 0) | ((vy & 2) ? vx << 3 : 0) | ((vy & 4) ? vx << 6 : 0);
             }
             avm[k] = msk;
         }
@@ -1940,23 +2028,6 @@ __global__ void __launch_bounds__(512)
         is_lds = ring0 + (unsigned)is_slot * (unsigned)(SLOTH * 2);                                                 \
     } while (0)
 
-    // tap validity of this lane's pixels (bit = tap index); 1x1: every tap valid
-    int vm[FM];
-#pragma unroll
-    for (int j = 0; j < FM; ++j) {
-        int msk = KS == 1 ? 1 : 0;
-        if (KS == 3) {
-            const int m = P0 + wm * TM + 16 * j + (lane & 15);
-            if (m < a.M) {
-                const int b = m / HoWo, rem = m - b * HoWo, oy = rem / a.Wo, ox = rem - oy * a.Wo;
-                const int iy0 = oy * a.stride - 1, ix0 = ox * a.stride - 1;
-#pragma unroll
-                for (int t = 0; t < 9; ++t)
-                    if ((unsigned)(iy0 + t / 3) < (unsigned)a.H && (unsigned)(ix0 + t % 3) < (unsigned)a.W) msk |= 1 << t;
-            }
-        }
-        vm[j] = msk;
-    }
 
     f4 acc[FN][FM];
 #pragma unroll
@@ -1972,6 +2043,24 @@ __global__ void __launch_bounds__(512)
 #pragma unroll
     for (int t = 0; t < (NSLOT - 1) * SUB; ++t)
         if (t < nsteps) GB_ISSUE();
+    // tap validity of this lane's pixels (bit = tap index); 1x1: every tap valid.  Computed here, under the latency of the first
+    // burst (see div_s)
+    int vm[FM];
+#pragma unroll
+    for (int j = 0; j < FM; ++j) {
+        int msk = KS == 1 ? 1 : 0;
+        if (KS == 3) {
+            const int m = P0 + wm * TM + 16 * j + (lane & 15);
+            if (m < a.M) {
+                const int b = div_s(m, HoWo, inv_howo), rem = m - b * HoWo, oy = div_s(rem, a.Wo, inv_wo), ox = rem - oy * a.Wo;
+                const int iy0 = oy * a.stride - 1, ix0 = ox * a.stride - 1;
+                const int vy = ((unsigned)iy0 < (unsigned)a.H ? 1 : 0) | ((unsigned)(iy0 + 1) < (unsigned)a.H ? 2 : 0) | ((unsigned)(iy0 + 2) < (unsigned)a.H ? 4 : 0);
+                const int vx = ((unsigned)ix0 < (unsigned)a.W ? 1 : 0) | ((unsigned)(ix0 + 1) < (unsigned)a.W ? 2 : 0) | ((unsigned)(ix0 + 2) < (unsigned)a.W ? 4 : 0);
+                msk = ((vy & 1) ? vx : 0) | ((vy & 2) ? vx << 3 : 0) | ((vy & 4) ? vx << 6 : 0);
+            }
+        }
+        vm[j] = msk;
+    }
     const int xr = lane & 7;                                       // BK 64: (row & 7) of every fragment row this lane reads
     const int nfat = (nsteps + SUB - 1) / SUB;                     // barriers: one per SUB K-steps
     for (int sf = 0; sf < nfat; ++sf) {
@@ -2122,6 +2211,7 @@ hipError_t launch_gbig1(ConvArgs &a, hipStream_t s)
     if ((size_t)a.H * a.W * (size_t)(a.M / (a.Ho * a.Wo) + 1) * (UP ? a.ldi2 : a.ldi) * 2 >= (1ull << 32) ||
         (size_t)a.CoutPad * KS * KS * a.Cin * 2 >= (1ull << 32))
         return hipErrorInvalidValue;
+    if (a.M >= (1 << 24)) return hipErrorInvalidValue;             // div_s: raster positions below 2^24
     a.m_tiles = rva_ceil_div(a.M, BM);
     k_conv_gbig<BM, BN, WGM, WGN, NSLOT, KS, BK, UP, HEAD, SUB><<<rva_ceil_div(a.m_tiles, 8) * 8 * a.n_tiles, 512, smem, s>>>(a);
     return hipGetLastError();
@@ -2968,8 +3058,13 @@ int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *wei
             RunArgs g{};
             g.in = a.in; g.ldi = ldi; g.w = a.w; g.bias = bias; g.out = a.out; g.ldo = ldo; g.res = a.res; g.ldr = ldr;
             g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.CoutPad = rva_ceil_div(Cout, 64) * 64; g.act = act; g.M = a.M;
-            if (variant == 90) ev = launch_run<256, 128, 4, 2, true>(g, s);       // run<256,128> without the padding selects
-            else if (variant == 91) ev = launch_run<256, 64, 4, 2, true>(g, s);   // run<256,64> without the padding selects
+            const char *nosel = getenv("RVA_NOSEL");      // the select-free kernels give wrong border pixels: opt-in per process
+            if (variant == 90) { if (nosel && nosel[0] == '1') ev = launch_run<256, 128, 4, 2, true>(g, s); }       // run<256,128> without the padding selects
+            else if (variant == 91) { if (nosel && nosel[0] == '1') ev = launch_run<256, 64, 4, 2, true>(g, s); }   // run<256,64> without the padding selects
+            else if (variant == 92) ev = launch_run<256, 64, 4, 2, false, true>(g, s);    // run kernels on the padded raster
+            else if (variant == 97) ev = launch_run<256, 128, 4, 2, false, true>(g, s);
+            else if (variant == 98) ev = launch_run<320, 64, 4, 2, false, true>(g, s);
+            else if (variant == 99) ev = launch_run<224, 128, 2, 4, false, true>(g, s);
         }
         if (ev == hipSuccess) return RVA_OK;
         (void)hipGetLastError();
@@ -3301,7 +3396,7 @@ int rva_conv1x1_head_f16(rva_ctx *ctx, const void *in, int ldi, const void *weig
 
 int rva_conv_cout_pad(int Cout) { return rva_ceil_div(Cout, 64) * 64; }
 
-int rva_conv_num_variants(void) { return RVA_CONV_VARIANTS; }
+int rva_conv_num_variants(void) { return RVA_CONV_VARIANTS_MAX; }
 
 int rva_stem_conv_f16(rva_ctx *ctx, const void *in_planar, const void *weights, const float *bias, void *out, int ldo,
                       int batch, int H, int W, int Cout, rva_stream_t stream_)
