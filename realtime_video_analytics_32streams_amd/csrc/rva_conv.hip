@@ -2962,7 +2962,7 @@ __global__ void __launch_bounds__(1024) k_stem2(Stem2Args a)
 
 }  // namespace
 
-#define RVA_CONV_VARIANTS 79
+#define RVA_CONV_VARIANTS 85
 #ifdef RVA_EXPERIMENTS
 #define RVA_CONV_VARIANTS_MAX 99      // 90..: timing-only experiment kernels of a private build (tools/exp_build.py), never in librva.so
 #else
@@ -2998,6 +2998,8 @@ int rva_dbg_read_stamps(unsigned long long *host) { return (int)hipMemcpyFromSym
 //          <256,64> <64,96> <128,96> <192,64> <256,96>; one barrier per 32-channel chunk (nine taps), one block per CU
 //   74..79 LDS-DMA gather kernel (as 33..39, two-slot ring) with SUB 64-channel K-steps per barrier: <BM,BN>xSUB = <128,128>x2 <128,64>x2
 //          <128,64>x3 <64,64>x4 <64,128>x3 <64,64>x2
+//   80..85 "long run" kernels on the padded raster (k_conv3_run<..., PADO>: no padding selects): <256,64> <256,128> <224,128> <320,64>
+//          <192,128> <128,64>
 int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *weights, const float *bias, void *out,
                           int ldo, const void *residual, int ldr, int batch, int H, int W, int Cin, int Cout, int ksize,
                           int stride, int act, int variant, rva_stream_t stream_);
@@ -3051,6 +3053,26 @@ int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *wei
             if (rc == RVA_OK) return rc;
         }
     }
+    if (variant >= 80 && variant <= 85) {
+        // "long run" kernels on the padded raster (no padding selects in the MFMA phase): see k_conv3_run<..., PADO>
+        hipError_t ev = hipErrorInvalidValue;
+        if (ksize == 3 && stride == 1) {
+            RunArgs g{};
+            g.in = a.in; g.ldi = ldi; g.w = a.w; g.bias = bias; g.out = a.out; g.ldo = ldo; g.res = a.res; g.ldr = ldr;
+            g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.CoutPad = rva_ceil_div(Cout, 64) * 64; g.act = act; g.M = a.M;
+            switch (variant) {
+            case 80: ev = launch_run<256, 64, 4, 2, false, true>(g, s); break;
+            case 81: ev = launch_run<256, 128, 4, 2, false, true>(g, s); break;
+            case 82: ev = launch_run<224, 128, 2, 4, false, true>(g, s); break;
+            case 83: ev = launch_run<320, 64, 4, 2, false, true>(g, s); break;
+            case 84: ev = launch_run<192, 128, 4, 2, false, true>(g, s); break;
+            default: ev = launch_run<128, 64, 2, 4, false, true>(g, s); break;
+            }
+        }
+        if (ev == hipSuccess) return RVA_OK;
+        (void)hipGetLastError();
+        return rva_fail(ctx, ev == hipErrorInvalidValue ? RVA_ERR_ARG : RVA_ERR_HIP, "conv variant %d not applicable here", variant);
+    }
 #ifdef RVA_EXPERIMENTS
     if (variant >= 90) {
         hipError_t ev = hipErrorInvalidValue;
@@ -3061,10 +3083,6 @@ int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *wei
             const char *nosel = getenv("RVA_NOSEL");      // the select-free kernels give wrong border pixels: opt-in per process
             if (variant == 90) { if (nosel && nosel[0] == '1') ev = launch_run<256, 128, 4, 2, true>(g, s); }       // run<256,128> without the padding selects
             else if (variant == 91) { if (nosel && nosel[0] == '1') ev = launch_run<256, 64, 4, 2, true>(g, s); }   // run<256,64> without the padding selects
-            else if (variant == 92) ev = launch_run<256, 64, 4, 2, false, true>(g, s);    // run kernels on the padded raster
-            else if (variant == 97) ev = launch_run<256, 128, 4, 2, false, true>(g, s);
-            else if (variant == 98) ev = launch_run<320, 64, 4, 2, false, true>(g, s);
-            else if (variant == 99) ev = launch_run<224, 128, 2, 4, false, true>(g, s);
         }
         if (ev == hipSuccess) return RVA_OK;
         (void)hipGetLastError();

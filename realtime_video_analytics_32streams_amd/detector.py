@@ -181,7 +181,7 @@ class HipYoloDetector(BaseDetector):
             from .engine import FusedYoloV8
             first = self._plans.get(shape) if self._slot else None
             plan = self._plans[key] = FusedYoloV8(self.net, shape[0], shape[1:], device=self.device, ctx=self.ctx,
-                                                  autotune=first is None)
+                                                  autotune=first is None, tune_overlap=getattr(self, "tune_overlap", 1))
             if first is not None:
                 plan.copy_tuning(first)
         return plan

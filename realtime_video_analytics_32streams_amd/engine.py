@@ -72,7 +72,8 @@ class _View:
 
 class FusedYoloV8:
     def __init__(self, net: YoloV8, batch: int, hw: Tuple[int, int] = (640, 640), device: Optional[torch.device] = None,
-                 ctx: Optional[N.Context] = None, autotune: bool = True):
+                 ctx: Optional[N.Context] = None, autotune: bool = True, tune_overlap: int = 1):
+        self.tune_overlap = int(tune_overlap)
         self.ctx = ctx or ops.context()
         self.dev = device or torch.device("cuda", self.ctx.device)
         self.B, self.H, self.W = batch, hw[0], hw[1]
@@ -395,6 +396,7 @@ class FusedYoloV8:
         h.update(b"per-layer times; in-plan pass opt-in, three overlapping passes")
         h.update(repr([os.environ.get(k, "") for k in ("RVA_SKIP_VARIANTS", "RVA_TUNE_IN_PLAN", "RVA_TUNE_OVERLAP", "RVA_TUNE_TOP",
                                                        "RVA_TUNE_WITHIN", "RVA_NO_STEM2", "RVA_HEAD_SPLIT")]).encode())
+        h.update(repr(int(os.environ.get("RVA_TUNE_LAYER_OVERLAP", getattr(self, "tune_overlap", 1)))).encode())
         return h.hexdigest()[:24]
 
     def _load_tuning(self) -> bool:
@@ -444,6 +446,41 @@ class FusedYoloV8:
         self._n_variants = int(N.lib().rva_conv_num_variants())
         skip = {int(v) for v in os.environ.get("RVA_SKIP_VARIANTS", "").replace(",", " ").split()}      # tuning aid: same-box A/B of kernel families
         cache = {}
+        # What a launch costs a pipeline with several ticks in flight is not its time alone on the chip but the share of the chip it
+        # holds for that time: a one-workgroup-per-CU kernel (120-150 KB of LDS) that is 15 % faster alone than a two-per-CU one
+        # leaves no room for the other chains' kernels while it runs.  tune_overlap = n >= 2 times every candidate as n launches
+        # side by side on the chains' own streams (behind a spin kernel, so that the host's launch rate stays out of the
+        # measurement) and keeps the variant with the lowest time PER LAUNCH; 1 = the launch alone (lowest latency: one tick at a
+        # time, the paced operating point).  PipelinedTicks sets it to its depth; RVA_TUNE_LAYER_OVERLAP overrides.
+        n_over = int(os.environ.get("RVA_TUNE_LAYER_OVERLAP", getattr(self, "tune_overlap", 1)))
+        lanes = ops.chain_streams(self.dev, n_over) if n_over >= 2 else []
+        spin = int(os.environ.get("RVA_TUNE_SPIN_CYCLES", "400000"))       # ~0.2 ms: every stream's launches are queued before any starts
+
+        def time_variant(variant) -> float:
+            torch.cuda.synchronize()
+            if not lanes:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    launch(stream, variant)
+                e1.record()
+                torch.cuda.synchronize()
+                return e0.elapsed_time(e1) / reps * 1e3
+            evs = []
+            for st in lanes:
+                with torch.cuda.stream(st):
+                    torch.cuda._sleep(spin)
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record()
+                    sp = C.c_void_p(st.cuda_stream)
+                    for _ in range(reps):
+                        launch(sp, variant)
+                    b.record()
+                    evs.append((a, b))
+            torch.cuda.synchronize()
+            # from the first stream's start to the last stream's end (the spins end within microseconds of each other)
+            first = evs[0][0]
+            return max(first.elapsed_time(b) for _, b in evs) / (reps * len(lanes)) * 1e3
         for launch, state, desc in self._tunable:
             if desc in cache:
                 state["variant"] = cache[desc][0]
@@ -453,14 +490,7 @@ class FusedYoloV8:
             for variant in range(1, self._n_variants + 1):
                 if variant in skip or launch(stream, variant) != N.RVA_OK:
                     continue
-                torch.cuda.synchronize()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(reps):
-                    launch(stream, variant)
-                e1.record()
-                torch.cuda.synchronize()
-                us = e0.elapsed_time(e1) / reps * 1e3
+                us = time_variant(variant)
                 timed.append((us, variant))
                 if us < best[1]:
                     best = (variant, us)

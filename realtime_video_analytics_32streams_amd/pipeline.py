@@ -454,6 +454,10 @@ class PipelinedTicks:
         # K1 of tick k+1 beside the 20x20 phase of tick k's forward pass (most CUs and most of the HBM bandwidth idle there)
         # instead of beside its stem / 80x80 layers: RVA_K1_GATE=1.  Off by default: see DESIGN.md (K1 in the pipeline).
         self.k1_gate = os.environ.get("RVA_K1_GATE", "0") == "1" and self.net_streams >= 2
+        # kernel selection objective of plans built from now on: launches timed `net_streams` at a time (see FusedYoloV8.autotune)
+        for d in pipe.detectors:
+            if is_fused(d) and not getattr(d, "_plans", None):
+                d.tune_overlap = max(self.net_streams, 1)
         ns = self.nslots
         self._phase_ev = [torch.cuda.Event() for _ in range(ns)]
         self._pending = [None] * ns           # per slot: what the stream-B part of that tick needs

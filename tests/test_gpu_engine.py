@@ -127,6 +127,7 @@ def test_every_conv_variant_agrees(shape):
         if k == 3 and stride == 1 and W <= 160:
             assert any(52 <= v <= 60 for v in ran), ran    # the long-run kernels took part
             assert any(67 <= v <= 73 for v in ran), ran    # the whole-chunk-per-barrier kernels took part
+            assert all(v in ran for v in (80, 81, 82, 83, 84, 85)), ran     # the long-run kernels on the padded raster took part
             if Cout % 96 == 0:
                 assert 70 in ran and 71 in ran, ran        # ... with 96-channel tiles
 

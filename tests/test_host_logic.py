@@ -401,3 +401,111 @@ def test_ultralytics_named_state_dict_loads(tmp_path):
     del bad["model.22.dfl.conv.weight"], bad["model.0.conv.weight"]
     with pytest.raises(KeyError, match="lacks"):
         Y.load_detector_state_dict(Y.build_detector_net("n", seed=5), bad)
+
+
+REF_CONFIGS = Path("/root/reference/config")
+REF_TEMPORAL = Path("/root/reference/sample-temporal-pipeline.yaml")
+
+
+@pytest.mark.skipif(not REF_CONFIGS.is_dir(), reason="the reference tree is not on this box (GPU box)")
+def test_reference_yaml_files_load_in_place():
+    """Every configuration file the reference ships (config/*.yaml, sample-temporal-pipeline.yaml) through ``load_config``, read
+    IN PLACE: each stream / detector / tracker field equals what the YAML says (known keys), defaults fill the rest, unknown
+    keys are dropped.  BASELINE configs[0] is config/pipeline-sim.yaml: its values are spelled out below
+    (/root/reference/config/pipeline-sim.yaml:6-30)."""
+    import dataclasses
+    files = sorted(REF_CONFIGS.glob("*.yaml")) + ([REF_TEMPORAL] if REF_TEMPORAL.is_file() else [])
+    assert len(files) >= 7
+    for f in files:
+        raw = yaml.safe_load(f.read_text())
+        cfg = C.load_config(f)
+        assert [s.name for s in cfg.streams] == [s["name"] for s in raw["streams"]], f.name
+        for s, rs in zip(cfg.streams, raw["streams"]):
+            for fld in dataclasses.fields(C.StreamConfig):
+                if fld.name in rs:
+                    assert getattr(s, fld.name) == rs[fld.name], (f.name, s.name, fld.name)
+            assert cfg.detector_for(s) is (cfg.detectors[s.detector_id] if s.detector_id else cfg.detector)
+        for name, rd in [("", raw.get("detector") or {})] + list((raw.get("detectors") or {}).items()):
+            d = cfg.detectors[name] if name else cfg.detector
+            for fld in dataclasses.fields(C.DetectorConfig):
+                if fld.name in rd:
+                    assert getattr(d, fld.name) == rd[fld.name], (f.name, name, fld.name)
+        for fld in dataclasses.fields(C.TrackerConfig):
+            if fld.name in (raw.get("tracker") or {}):
+                assert getattr(cfg.tracker, fld.name) == raw["tracker"][fld.name], (f.name, fld.name)
+    sim = C.load_config(REF_CONFIGS / "pipeline-sim.yaml")
+    assert len(sim.streams) == 1 and sim.max_concurrent_streams == 4 and sim.stats_interval_seconds == 10
+    s = sim.streams[0]
+    assert (s.name, s.url, s.enabled, s.target_fps, s.batch_size, s.warmup_seconds, s.reconnect_backoff) == \
+        ("sim-1", "/app/data/samples/demo.mp4", True, 12, 1, 0.5, 2.0)
+    d = sim.detector
+    assert (d.model_path, d.device, d.backend, d.confidence_threshold, d.iou_threshold, d.half, d.warmup) == \
+        ("/app/models/yolo/yolov8n.pt", "cpu", "ultralytics", 0.35, 0.5, False, False)
+    assert (sim.tracker.type, sim.tracker.max_age, sim.tracker.max_iou_distance, sim.tracker.min_hits) == ("byte_track", 30, 0.5, 1)
+    if REF_TEMPORAL.is_file():
+        t = C.load_config(REF_TEMPORAL)
+        cl = t.detectors["temporal_cnn_lstm"]
+        assert (cl.model_type, cl.sequence_length, cl.sequence_stride, cl.temporal_overlap, cl.half) == ("cnn_lstm", 16, 2, 0.5, False)
+        assert list(cl.input_size) == [224, 224] and cl.num_action_classes == 400
+
+
+@pytest.mark.skipif(not REF_CONFIGS.is_dir(), reason="the reference tree is not on this box (GPU box)")
+def test_reference_config_routed_to_this_library_fails_with_the_documented_errors():
+    """configs[0] as the reference ships it names the reference's own backend and a container path.  Routed to this library
+    unchanged: ``backend: ultralytics`` -> the 'belongs to the reference implementation' RuntimeError of create_detector
+    (detector.py:496-502: a backend whose runtime is missing raises); the stream ``/app/data/samples/demo.mp4`` -> 'Unable to
+    open stream' (video_stream.py:78-79), whether because the decoder library is absent or because the file is."""
+    import dataclasses
+    from realtime_video_analytics_32streams_amd.detector import create_detector
+    from realtime_video_analytics_32streams_amd.video_stream import RocDecodeStream
+    sim = C.load_config(REF_CONFIGS / "pipeline-sim.yaml")
+    with pytest.raises(RuntimeError, match="belongs to the reference implementation"):
+        create_detector(sim.detector)
+    with pytest.raises(RuntimeError, match="Unable to open stream sim-1"):
+        RocDecodeStream(sim.streams[0]).open_sync()
+    # the one edit a maintainer makes (INTEGRATION.md): backend -> hip.  Without a GPU that fails loudly too -- never a CPU path.
+    hip = dataclasses.replace(sim.detector, backend="hip")
+    hip.validate()
+    import torch
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            create_detector(hip)
+
+
+def test_id_sync_dead_rank_makes_the_survivor_exit_nonzero(tmp_path):
+    """Failure path of the id exchange (dist.py): rank 1 dies after three exchanges; rank 0's next all-gather must not block for
+    ever -- it exits with dist.EXIT_PEER_LOST within the process-group timeout (RVA_DIST_TIMEOUT_S), and says why on stderr."""
+    script = textwrap.dedent(f"""
+        import os, sys, time
+        sys.path.insert(0, {str(ROOT)!r})
+        import torch
+        from realtime_video_analytics_32streams_amd.dist import IdSync, init_from_env
+        rank, world, _ = init_from_env("gloo")
+        sync = IdSync(4, torch.device("cpu"))
+        for t in range(1000):
+            if rank == 1 and t == 3:
+                os._exit(0)                      # the peer vanishes without a goodbye
+            sync.all_gather_counts(torch.full((4,), t, dtype=torch.int32))
+        print("unreachable: the exchange kept going without its peer")
+    """)
+    sp = tmp_path / "worker.py"
+    sp.write_text(script)
+    port = _free_port()
+    procs = []
+    import time
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   RVA_DIST_TIMEOUT_S="8")
+        procs.append(subprocess.Popen([sys.executable, str(sp)], env=env, stderr=subprocess.PIPE, stdout=subprocess.PIPE, text=True))
+    t0 = time.monotonic()
+    try:
+        out0, err0 = procs[0].communicate(timeout=90)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    from realtime_video_analytics_32streams_amd import dist as rdist
+    assert procs[1].wait(timeout=10) == 0
+    assert procs[0].returncode == rdist.EXIT_PEER_LOST, (procs[0].returncode, err0[-400:])
+    assert "unreachable" not in out0 and "id exchange failed" in err0 and "exiting with status" in err0
+    assert time.monotonic() - t0 < 60

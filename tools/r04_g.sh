@@ -4,7 +4,7 @@ export TMPDIR=/tmp PYTHONPATH=$ROOT RVA_TUNE_CACHE_DIR=/tmp/rva_tune
 O=$ROOT/gpurun_out/r04g; rm -rf $O; mkdir -p $O
 timeout -k 10 900 python3 -m pytest tests/test_gpu_engine.py -x -q > $O/pytest_engine.log 2>&1; rc=$?; echo "pytest engine rc=$rc"; tail -5 $O/pytest_engine.log
 [ $rc -eq 0 ] || exit 1
-for spec in "128 128 3 1 40 32 52 91 56 90" "256 256 3 1 20 32 52 91 69" "128 128 3 1 80 32 52 91 31"; do
+for spec in "128 128 3 1 40 32 52 80 56 81 58 82 84 85"; do
   RVA_NOSEL=1 RVA_LIB_PATH=$ROOT/tools/_dbg/librva_exp.so timeout -k 10 120 python3 tools/sweep_run.py $spec >> $O/nosel2.txt 2>&1; echo "sweep rc=$?"
 done
 grep -v amdgpu.ids $O/nosel2.txt
