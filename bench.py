@@ -72,8 +72,11 @@ def parse():
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark = True")
     ap.add_argument("--no-graph", action="store_true",
                     help="launch every kernel eagerly instead of replaying the captured hipGraph of the post-process / tracker tail")
-    ap.add_argument("--net-graph", action="store_true",
-                    help="also replay the detector network from a captured hipGraph (serialises its concurrent detect branches)")
+    ap.add_argument("--net-graph", nargs="?", const="on", default="auto", choices=["auto", "on", "off"],
+                    help="how the detector network of a tick is launched: 'off' = ~75-110 eager launches per tick (~0.5 ms of host "
+                         "time), 'on' = one hipGraph replay (~0.15 ms; the graph executor costs the GPU 2-5 %%), 'auto' (default) = "
+                         "both are timed during warm-up and the faster one runs the timed region (the graph wins where the host is "
+                         "the limit: YOLOv8n x 4 streams)")
     ap.add_argument("--depth", type=int, default=None, choices=[1, 2, 3, 4, 5, 6, 7, 8],
                     help="ticks in flight, each a chain on its own HIP stream: 3 (default) measured +3..7 %% frames/s over 2 at "
                          "+1.6 ms p99 latency; the runtime has four hardware lanes for streams, so a fourth chain shares one with the "
@@ -245,7 +248,8 @@ def main():
     # autotunes the plan eagerly, the second one captures the hipGraphs, the rest replay them -----------------
     use_graph = not args.no_graph
     from realtime_video_analytics_32streams_amd.pipeline import PipelinedTicks
-    runner = PipelinedTicks(pipe, depth=args.depth, use_graph=use_graph, net_graph=args.net_graph)
+    runner = PipelinedTicks(pipe, depth=args.depth, use_graph=use_graph, net_graph=args.net_graph != "off")
+    runner.replay_net = args.net_graph == "on" and runner.net_graph
     # at least 20 untimed ticks: the first one builds and tunes the plan, the second builds the odd ticks' plan, the third captures
     # the hipGraphs, and the clocks / caches of a fresh process take a few more to settle (20 timed ticks after 5 warm-up ticks
     # read 3 % lower than after 30); the timed region below is exactly --steps ticks either way
@@ -254,6 +258,29 @@ def main():
         runner.submit()
         runner.collect()
     torch.cuda.synchronize()
+    net_launch = {"mode": "hipGraph" if runner.replay_net else "eager", "chosen_by": "--net-graph " + args.net_graph}
+    if args.net_graph == "auto" and runner.net_graph and runner._captured:
+        def rate(n=40):
+            done = 0
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(n):
+                if k - done == runner.depth:
+                    runner.collect(); done += 1
+                runner.submit()
+            while done < n:
+                runner.collect(); done += 1
+            return S * n / (time.perf_counter() - t0)
+        trial = {}
+        for mode in (False, True, False, True):               # interleaved: eager, graph, eager, graph
+            runner.replay_net = mode
+            rate(10)
+            trial.setdefault(mode, []).append(rate())
+        eager_fps, graph_fps = max(trial[False]), max(trial[True])
+        runner.replay_net = graph_fps > eager_fps * 1.01
+        net_launch = {"mode": "hipGraph" if runner.replay_net else "eager", "chosen_by": "warm-up trial (2 x 40 ticks each, untimed)",
+                      "eager_frames_per_s": round(eager_fps, 1), "graph_frames_per_s": round(graph_fps, 1)}
+        torch.cuda.synchronize()
 
     # ---- timed region: exactly K steps, per-stage HIP events on the launch stream ---------------------
     K = args.steps
@@ -383,7 +410,7 @@ def main():
         "max_latency_ms": round(float(lat.max()) * 1e3, 3), "latency_samples": int(K),
         "host_submit_us_per_tick": {"mean": round(float(t_sub.mean()) * 1e6, 1), "p50": round(float(np.percentile(t_sub, 50)) * 1e6, 1),
                                     "what": "wall time inside PipelinedTicks.submit() on the host thread (every launch of the tick enqueued)"},
-        "ticks_in_flight": runner.depth, "network_streams": runner.net_streams, "warmup_ticks_run": warm_ticks, "hip_graph": bool(use_graph), "hip_graph_scope": ("network + tail" if args.net_graph else ("post-process / tracker tail (networks launched eagerly; a tick is one chain on its own stream, consecutive ticks rotate over %d streams)" % runner.net_streams if runner.net_streams >= 2 else "post-process / tracker tail (network launched eagerly: concurrent detect branches)")) if use_graph else None, "realtime_32x30fps": bool(fps / world >= 30.0 * S and np.percentile(lat, 99) < 1 / 30),
+        "ticks_in_flight": runner.depth, "network_streams": runner.net_streams, "warmup_ticks_run": warm_ticks, "hip_graph": bool(use_graph), "network_launch": net_launch, "hip_graph_scope": ("network + tail" if runner.replay_net else ("post-process / tracker tail (networks launched eagerly; a tick is one chain on its own stream, consecutive ticks rotate over %d streams)" % runner.net_streams if runner.net_streams >= 2 else "post-process / tracker tail (network launched eagerly: concurrent detect branches)")) if use_graph else None, "realtime_32x30fps": bool(fps / world >= 30.0 * S and np.percentile(lat, 99) < 1 / 30),
         "stages_ms": {"k1_preprocess": round(float(k1_ms), 4), "detector": round(float(net_ms), 4),
                       "k2k3_postprocess": round(float(post_ms), 4), "k4_tracker": round(float(trk_ms), 4)},
         "detections_per_frame": round(dets_emitted / S, 2), "tracks_per_stream": round(n_tracks / (K * S), 2),

@@ -345,6 +345,57 @@ int rva_yolo_head3_f16(rva_ctx *ctx, const void *const *box_logits, const int32_
                        int anchors_total, const float *strides, rva_stream_t stream);
 
 /* ----------------------------------------------------------------------------------------------
+ * The fused YOLOv8 detector as ONE object (round 4) -- replaces `self.session.run` of the reference's ONNX Runtime
+ * backend (/root/reference/src/realtime_analytics/detector.py:597-609; the network it runs is the exported ultralytics graph,
+ * detector.py:575-586) for `half: true`.
+ *
+ * rva_yolov8_plan_create: `convs` = the network's n_convs convolutions with BatchNorm folded, in MODULE ORDER, each in the
+ *   checkpoint's own layout (fp32 host arrays, weight [cout][cin][k][k], bias [cout] or NULL).  Module order: b0, b1, C2f(b2), b3,
+ *   C2f(b4), b5, C2f(b6), b7, C2f(b8), SPPF(b9) = cv1 cv2, C2f(h12), C2f(h15), h16, C2f(h18), h19, C2f(h21), detect.box[0..2][0..2],
+ *   detect.cls[0..2][0..2]; C2f(x) = cv1, cv2, then cv1 cv2 of every bottleneck (ultralytics model.0 .. model.22).  The call
+ *   checks every shape against the descriptor (RVA_ERR_ARG names the first convolution that does not fit), packs the weights
+ *   for the kernels above, allocates all activation buffers in HBM and lays down the static list of launches.
+ * rva_yolov8_plan_run: input = fp16 planar [batch,3,height,width] (what rva_preprocess_* writes), output = fp16
+ *   [batch, 4+nc, anchors] (what rva_postprocess_batch reads; anchors = H/8*W/8 + H/16*W/16 + H/32*W/32); every launch of the
+ *   forward pass goes to `stream`, no host synchronisation, no allocation: capturable.  _run_lanes additionally forks the
+ *   stride-8 / stride-16 detect branches onto two side streams (events inside the plan) and joins them at the end: +6 % for one
+ *   pass at a time; with several passes in flight use _run.  _run_range(first, last) replays steps [first, last) (a caller that
+ *   wants an event at `quiet_step`, where the pass enters its 20x20 layers).
+ * Kernel selection: every convolution step ("tunable") carries a kernel variant of rva_conv2d_nhwc_f16_v (0 = heuristic).
+ *   A tuner times rva_yolov8_plan_launch_tunable(index, variant) on the plan's own buffers (RVA_ERR_ARG = variant does not
+ *   apply to that layer) and fixes its choice with _set_variant; _tunable_desc gives "Cin->Cout kKsS HxW" (the key of a
+ *   persisted selection).  Results do not depend on the variant beyond fp32 summation order.
+ * -------------------------------------------------------------------------------------------- */
+#define RVA_PLAN_NO_STEM2 1   /* rva_yolov8_desc.flags: stem and first downsampling convolution as two launches (A/B switch) */
+typedef struct rva_yolov8_plan rva_yolov8_plan;
+typedef struct rva_yolov8_desc {
+    int32_t batch, height, width;     /* input tensor; height and width multiples of 32 */
+    int32_t widths[5];                /* c1..c5 (YOLOv8s: 32 64 128 256 512) */
+    int32_t depth_backbone[4];        /* bottlenecks of the C2f blocks b2, b4, b6, b8 (YOLOv8s: 1 2 2 1) */
+    int32_t depth_head;               /* bottlenecks of h12, h15, h18, h21 (YOLOv8s: 1) */
+    int32_t nc, reg_max;              /* classes (multiple of 8), DFL bins (16) */
+    int32_t n_convs;                  /* length of `convs` */
+    int32_t flags;
+} rva_yolov8_desc;
+typedef struct rva_conv_weights {
+    const float *weight;              /* [cout][cin][k][k] */
+    const float *bias;                /* [cout] or NULL */
+    int32_t cout, cin, k, stride;
+} rva_conv_weights;
+int rva_yolov8_plan_create(rva_ctx *ctx, const rva_yolov8_desc *desc, const rva_conv_weights *convs, rva_yolov8_plan **out);
+void rva_yolov8_plan_destroy(rva_yolov8_plan *plan);
+int rva_yolov8_plan_info(const rva_yolov8_plan *plan, int32_t *anchors, int32_t *out_rows, int32_t *n_steps, int32_t *n_tunable,
+                         int32_t *quiet_step);
+int rva_yolov8_plan_run(rva_yolov8_plan *plan, const void *input, void *output, rva_stream_t stream);
+int rva_yolov8_plan_run_lanes(rva_yolov8_plan *plan, const void *input, void *output, rva_stream_t stream, rva_stream_t side1,
+                              rva_stream_t side2);
+int rva_yolov8_plan_run_range(rva_yolov8_plan *plan, const void *input, void *output, int first, int last, rva_stream_t stream);
+int rva_yolov8_plan_tunable_desc(const rva_yolov8_plan *plan, int index, char *buf, int len);
+int rva_yolov8_plan_launch_tunable(rva_yolov8_plan *plan, int index, int variant, void *output, rva_stream_t stream);
+int rva_yolov8_plan_set_variant(rva_yolov8_plan *plan, int index, int variant);
+int rva_yolov8_plan_get_variant(const rva_yolov8_plan *plan, int index);
+
+/* ----------------------------------------------------------------------------------------------
  * K5 motion gate -- replaces MotionFilter.should_process (utils/frame_filter.py:26-40)
  * for a tick of NV12 surfaces: gray -> 5x5 Gaussian -> |diff| against prev_blur[i] -> counts[i] = number of
  * pixels with diff > 25 (device int32[n]; -1 where prev_blur[i] is NULL = first frame of that stream).

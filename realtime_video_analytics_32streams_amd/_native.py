@@ -18,7 +18,7 @@ PKG = Path(__file__).resolve().parent
 ROOT = PKG.parent
 CSRC = PKG / "csrc"
 LIB_PATH = Path(os.environ["RVA_LIB_PATH"]) if os.environ.get("RVA_LIB_PATH") else PKG / "librva.so"   # override: diagnostic builds (tools/)
-SOURCES = ["rva_ctx.hip", "rva_preprocess.hip", "rva_postprocess.hip", "rva_tracker.hip", "rva_conv.hip", "rva_gates.hip",
+SOURCES = ["rva_ctx.hip", "rva_preprocess.hip", "rva_postprocess.hip", "rva_tracker.hip", "rva_conv.hip", "rva_plan.hip", "rva_gates.hip",
            "rva_decode.hip", "rva_preview.hip"]
 # -ffp-contract=off: parity kernels must not fuse a*b+c (SURVEY.md hard part 4)
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off",
@@ -40,6 +40,22 @@ class Letterbox(C.Structure):
     def as_meta(self) -> dict:
         """The ``meta`` dict of detector.py:259-263."""
         return {"orig_shape": (self.src_h, self.src_w), "scale": self.scale, "pad": (self.pad_left, self.pad_top)}
+
+
+class YoloV8Desc(C.Structure):
+    """``rva_yolov8_desc`` (include/rva.h)."""
+    _fields_ = [("batch", C.c_int32), ("height", C.c_int32), ("width", C.c_int32), ("widths", C.c_int32 * 5),
+                ("depth_backbone", C.c_int32 * 4), ("depth_head", C.c_int32), ("nc", C.c_int32), ("reg_max", C.c_int32),
+                ("n_convs", C.c_int32), ("flags", C.c_int32)]
+
+
+class ConvWeights(C.Structure):
+    """``rva_conv_weights`` (include/rva.h): one convolution in the checkpoint's own fp32 layout."""
+    _fields_ = [("weight", C.POINTER(C.c_float)), ("bias", C.POINTER(C.c_float)), ("cout", C.c_int32), ("cin", C.c_int32),
+                ("k", C.c_int32), ("stride", C.c_int32)]
+
+
+RVA_PLAN_NO_STEM2 = 1
 
 
 def _stale() -> bool:
@@ -157,6 +173,16 @@ def lib() -> C.CDLL:
         "rva_upsample2x_nhwc_f16": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
         "rva_yolo_head_f16": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_int, C.c_float, _P]),
+        "rva_yolov8_plan_create": (C.c_int, [_P, C.POINTER(YoloV8Desc), C.POINTER(ConvWeights), C.POINTER(_P)]),
+        "rva_yolov8_plan_destroy": (None, [_P]),
+        "rva_yolov8_plan_info": (C.c_int, [_P, i32p, i32p, i32p, i32p, i32p]),
+        "rva_yolov8_plan_run": (C.c_int, [_P, _P, _P, _P]),
+        "rva_yolov8_plan_run_lanes": (C.c_int, [_P, _P, _P, _P, _P, _P]),
+        "rva_yolov8_plan_run_range": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P]),
+        "rva_yolov8_plan_tunable_desc": (C.c_int, [_P, C.c_int, C.c_char_p, C.c_int]),
+        "rva_yolov8_plan_launch_tunable": (C.c_int, [_P, C.c_int, C.c_int, _P, _P]),
+        "rva_yolov8_plan_set_variant": (C.c_int, [_P, C.c_int, C.c_int]),
+        "rva_yolov8_plan_get_variant": (C.c_int, [_P, C.c_int]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError here == header/library mismatch: fail loudly
@@ -180,6 +206,9 @@ EXPORTS = [
     "rva_decoder_next_frame", "rva_decoder_release", "rva_motion_nv12_batch", "rva_motion_nv12_masked_batch", "rva_motion_bgr_batch",
     "rva_preprocess_nv12_masked_batch", "rva_resize_nv12_to_bgr_batch", "rva_tracker_set_box_scale", "rva_conv_cout_pad", "rva_conv_num_variants", "rva_conv2d_nhwc_f16", "rva_conv2d_nhwc_f16_v", "rva_stem_conv_f16", "rva_stem2_f16",
     "rva_conv1x1_head_f16", "rva_conv1x1_upcat_f16", "rva_sppf_pool3_nhwc_f16", "rva_maxpool5_nhwc_f16", "rva_upsample2x_nhwc_f16", "rva_yolo_head_f16", "rva_yolo_head3_f16",
+    "rva_yolov8_plan_create", "rva_yolov8_plan_destroy", "rva_yolov8_plan_info", "rva_yolov8_plan_run", "rva_yolov8_plan_run_lanes",
+    "rva_yolov8_plan_run_range", "rva_yolov8_plan_tunable_desc", "rva_yolov8_plan_launch_tunable", "rva_yolov8_plan_set_variant",
+    "rva_yolov8_plan_get_variant",
 ]
 
 

@@ -1,33 +1,31 @@
-"""Fused YOLOv8 execution plan on the librva detector primitives.
+"""Fused YOLOv8 execution plan: the tuner and a thin caller of ``rva_yolov8_plan_*`` (include/rva.h).
 
-Takes the seeded/loaded ``yolov8.YoloV8`` module (BatchNorm folded) as the weight container and
-runs the same graph as a static list of HIP launches on NHWC fp16 buffers:
+The plan itself -- weight packing, the NHWC fp16 activation buffers, the static list of launches (one per Conv-BN-SiLU;
+``torch.cat`` / ``chunk`` / upsample never materialise), the fork / join of the detect branches -- is built and replayed in C
+(``csrc/rva_plan.hip``): one ABI call per forward pass.  What stays here:
 
-  * every Conv-BN-SiLU is ONE launch (MFMA implicit GEMM, bias + SiLU [+ residual] epilogue);
-  * ``torch.cat`` / ``chunk`` never materialise: producers write channel slices of pre-allocated
-    concat buffers and consumers read slices through a row stride (C2f, SPPF, FPN joins);
-  * SPPF max-pools, FPN upsampling and the DFL/sigmoid decode are small NHWC kernels;
-  * output is the same ``[B, 4+nc, A]`` fp16 tensor the torch module returns, so everything
-    downstream (K2/K3/K4) and every parity test is unchanged.
+  * handing the seeded / loaded ``yolov8.YoloV8`` module (BatchNorm folded) to ``rva_yolov8_plan_create`` as a list of
+    convolutions in module order;
+  * the per-layer kernel selection: every applicable variant of every convolution step is timed on the plan's own buffers
+    through ``rva_yolov8_plan_launch_tunable`` and the choice fixed with ``rva_yolov8_plan_set_variant``; the selection is
+    persisted per (device, library build, plan shape);
+  * the result tensors (a pipelined caller alternates several).
 
-The plan has no host synchronisation and allocates nothing after construction, so a whole tick can
-be captured into a hipGraph.  Self-parity against the torch module is a test (fp16 tolerance).
+Output: the same ``[B, 4+nc, A]`` fp16 tensor the torch module returns, so everything downstream (K2/K3/K4) and every parity
+test is unchanged.  No host synchronisation and no allocation after construction: a whole tick can be captured into a hipGraph.
 """
 from __future__ import annotations
 
 import ctypes as C
 import time
-from typing import Callable, Dict, List, Optional, Tuple
+from typing import Dict, List, Optional, Tuple
 
+import numpy as np
 import torch
 
 from . import _native as N
 from . import ops
-from .yolov8 import C2f, ConvBnAct, SPPF, YoloV8
-
-
-def _p(t: torch.Tensor) -> C.c_void_p:
-    return C.c_void_p(t.data_ptr())
+from .yolov8 import C2f, ConvBnAct, YoloV8
 
 
 _LIB_DIGEST: Optional[str] = None
@@ -49,338 +47,107 @@ def _tuning_dir():
     return Path(d) if d else Path(os.environ.get("XDG_CACHE_HOME", str(Path.home() / ".cache"))) / "rva_amd" / "autotune"
 
 
-class _View:
-    """A channel slice of an NHWC buffer: (tensor [M, ld], channel offset, channels)."""
+def module_order_convs(net: YoloV8) -> list:
+    """The convolutions of a fused ``YoloV8`` in the module order ``rva_yolov8_plan_create`` consumes (include/rva.h)."""
+    def c2f(m: C2f):
+        out = [m.cv1, m.cv2]
+        for b in m.m:
+            out += [b.cv1, b.cv2]
+        return out
+    mods = [net.b0, net.b1, *c2f(net.b2), net.b3, *c2f(net.b4), net.b5, *c2f(net.b6), net.b7, *c2f(net.b8), net.b9.cv1, net.b9.cv2,
+            *c2f(net.h12), *c2f(net.h15), net.h16, *c2f(net.h18), net.h19, *c2f(net.h21)]
+    for branch in (net.detect.box, net.detect.cls):
+        for seq in branch:
+            mods += [seq[0], seq[1], seq[2]]
+    return [m.conv if isinstance(m, ConvBnAct) else m for m in mods]
 
-    __slots__ = ("buf", "off", "ch")
 
-    def __init__(self, buf: torch.Tensor, off: int, ch: int):
-        self.buf, self.off, self.ch = buf, off, ch
+class _VariantCell:
+    """``state["variant"]`` of one tunable step, stored in the C plan."""
 
-    @property
-    def ld(self) -> int:
-        return int(self.buf.shape[-1])
+    __slots__ = ("eng", "idx")
 
-    @property
-    def ptr(self) -> C.c_void_p:
-        return C.c_void_p(self.buf.data_ptr() + 2 * self.off)
+    def __init__(self, eng, idx):
+        self.eng, self.idx = eng, idx
 
-    def sub(self, off: int, ch: int) -> "_View":
-        assert off + ch <= self.ch
-        return _View(self.buf, self.off + off, ch)
+    def __getitem__(self, key):
+        assert key == "variant"
+        return int(self.eng.L.rva_yolov8_plan_get_variant(self.eng.handle, self.idx))
+
+    def __setitem__(self, key, value):
+        assert key == "variant"
+        self.eng.ctx.check(self.eng.L.rva_yolov8_plan_set_variant(self.eng.handle, self.idx, int(value)), "rva_yolov8_plan_set_variant")
 
 
 class FusedYoloV8:
     def __init__(self, net: YoloV8, batch: int, hw: Tuple[int, int] = (640, 640), device: Optional[torch.device] = None,
                  ctx: Optional[N.Context] = None, autotune: bool = True, tune_overlap: int = 1):
+        import os
         self.tune_overlap = int(tune_overlap)
         self.ctx = ctx or ops.context()
         self.dev = device or torch.device("cuda", self.ctx.device)
         self.B, self.H, self.W = batch, hw[0], hw[1]
         assert hw[0] % 32 == 0 and hw[1] % 32 == 0
         net = net.fuse()
-        self._net = net                     # kept for the twin plan of the in-plan kernel selection
+        self._net = net                     # kept for the twin plans of the in-plan kernel selection
         self.nc = net.nc
         self.L = N.lib()
-        self._keep: List[torch.Tensor] = []
-        self._steps: List[Callable[[C.c_void_p], None]] = []
-        self._lane_of: List[int] = []       # per step: 0 = main stream, k > 0 = side stream k (detect-head branches)
-        self._lane = 0
-        import os
-        self._split_branches = os.environ.get("RVA_HEAD_SPLIT", "0") == "1"     # measured: no gain over one lane per level (profiles/r02_head_lanes_ab.txt)
-        self._forks: Dict[int, Tuple[int, int]] = {}   # side lane -> (parent lane, step index at which it forks off the parent)
+        convs = module_order_convs(net)
+        keep, arr = [], (N.ConvWeights * len(convs))()
+        for i, c in enumerate(convs):
+            w = np.ascontiguousarray(c.weight.detach().float().cpu().numpy())
+            b = None if c.bias is None else np.ascontiguousarray(c.bias.detach().float().cpu().numpy())
+            keep += [w, b]
+            arr[i].weight = w.ctypes.data_as(C.POINTER(C.c_float))
+            arr[i].bias = b.ctypes.data_as(C.POINTER(C.c_float)) if b is not None else None
+            arr[i].cout, arr[i].cin, arr[i].k, arr[i].stride = int(w.shape[0]), int(w.shape[1]), int(w.shape[2]), int(c.stride[0])
+        d = N.YoloV8Desc()
+        d.batch, d.height, d.width = batch, hw[0], hw[1]
+        d.widths[:] = [net.b0.conv.out_channels, net.b1.conv.out_channels, net.b3.conv.out_channels, net.b5.conv.out_channels,
+                       net.b7.conv.out_channels]
+        d.depth_backbone[:] = [len(net.b2.m), len(net.b4.m), len(net.b6.m), len(net.b8.m)]
+        d.depth_head = len(net.h12.m)
+        assert len(net.h15.m) == len(net.h18.m) == len(net.h21.m) == d.depth_head
+        d.nc, d.reg_max, d.n_convs = net.nc, net.detect.reg_max, len(convs)
+        d.flags = N.RVA_PLAN_NO_STEM2 if os.environ.get("RVA_NO_STEM2", "0") == "1" else 0
+        h = C.c_void_p()
+        with torch.cuda.device(self.dev):
+            self.ctx.check(self.L.rva_yolov8_plan_create(self.ctx.handle, C.byref(d), arr, C.byref(h)), "rva_yolov8_plan_create")
+        self.handle = h
+        del keep
+        info = [C.c_int32() for _ in range(5)]
+        self.ctx.check(self.L.rva_yolov8_plan_info(h, *[C.byref(v) for v in info]), "rva_yolov8_plan_info")
+        self.A, rows, self._n_steps, n_tun, self.quiet_step = (int(v.value) for v in info)
+        assert rows == 4 + self.nc
+        self.out = torch.empty((batch, rows, self.A), dtype=torch.float16, device=self.dev)
+        self._outs = {0: self.out}
+        self.fused_stem = d.flags == 0 and tuple(d.widths[:2]) == (32, 64)
+        # (launch(stream, variant) -> rc, state["variant"], "Cin->Cout kKsS HxW") per convolution step, as the tuner and the tools use them
         self._tunable = []
-        self._build(net)
-        self._lane_of += [self._lane] * (len(self._steps) - len(self._lane_of))
-        self._side = {}                     # lane -> torch.cuda.Stream, created on first use
-        import os
+        buf = C.create_string_buffer(96)
+        for i in range(n_tun):
+            self.ctx.check(self.L.rva_yolov8_plan_tunable_desc(h, i, buf, 96), "rva_yolov8_plan_tunable_desc")
+
+            def launch(stream, variant, i=i):
+                return self.L.rva_yolov8_plan_launch_tunable(self.handle, i, variant, C.c_void_p(self.out.data_ptr()), stream)
+            self._tunable.append((launch, _VariantCell(self, i), buf.value.decode()))
+        self._side = None                   # two side streams for the detect branches, created on first use
+        self._forks = bool(self.fused_head_lanes())
         self.concurrent_heads = os.environ.get("RVA_SERIAL_HEADS") != "1"      # A/B switch for measurements
         if autotune:
             self.autotune()
 
-    # -- weight preparation ---------------------------------------------------------------------------
-    def _conv_params(self, conv):
-        """``conv``: one Conv2d, or a list of Conv2d with equal Cin / kernel / stride whose outputs are concatenated
-        along the channel axis (one launch for sibling convolutions that read the same tensor)."""
-        convs = list(conv) if isinstance(conv, (list, tuple)) else [conv]
-        conv = convs[0]
-        assert all(c.kernel_size == conv.kernel_size and c.stride == conv.stride and c.in_channels == conv.in_channels
-                   for c in convs)
-        w = torch.cat([c.weight.detach().float() for c in convs], 0)        # [Cout, Cin, k, k]
-        cout, cin, k, _ = w.shape
-        cpad = self.L.rva_conv_cout_pad(cout)
-        cinp = (cin + 31) // 32 * 32
-        wp = torch.zeros((cpad, k * k, cinp), dtype=torch.float16)
-        wp[:cout, :, :cin] = w.permute(0, 2, 3, 1).reshape(cout, k * k, cin).half()
-        bp = torch.zeros((cpad,), dtype=torch.float32)
-        o = 0
-        for c in convs:
-            if c.bias is not None:
-                bp[o:o + c.out_channels] = c.bias.detach().float()
-            o += c.out_channels
-        wp, bp = wp.to(self.dev).contiguous(), bp.to(self.dev).contiguous()
-        self._keep += [wp, bp]
-        return wp, bp, cin, cout, k, conv.stride[0]
+    def fused_head_lanes(self) -> bool:
+        """Whether the plan has detect branches that may run on side streams (head decode fused into the branches)."""
+        return any(d.startswith("head1:") for _, _, d in self._tunable)
 
-    def _buf(self, m: int, ch: int) -> torch.Tensor:
-        t = torch.zeros((m, ch), dtype=torch.float16, device=self.dev)
-        self._keep.append(t)
-        return t
-
-    # -- step emitters --------------------------------------------------------------------------------
-    def _conv(self, mod, src: _View, dst: _View, h: int, w: int, res: Optional[_View] = None):
-        mods = list(mod) if isinstance(mod, (list, tuple)) else [mod]
-        acts = {1 if isinstance(m, ConvBnAct) and m.act else 0 for m in mods}
-        assert len(acts) == 1, "fused sibling convolutions must share the activation"
-        act = acts.pop()
-        wp, bp, cin, cout, k, stride = self._conv_params([m.conv if isinstance(m, ConvBnAct) else m for m in mods])
-        assert cin == src.ch and cout == dst.ch, (cin, src.ch, cout, dst.ch)
-        B, L, ctx = self.B, self.L, self.ctx
-
-        state = {"variant": 0}
-
-        def launch(stream, variant):
-            return L.rva_conv2d_nhwc_f16_v(ctx.handle, src.ptr, src.ld, _p(wp), _p(bp), dst.ptr, dst.ld,
-                                           res.ptr if res else None, res.ld if res else 0, B, h, w, cin, cout, k, stride, act,
-                                           variant, stream)
-
-        def run(stream):
-            ctx.check(launch(stream, state["variant"]), "rva_conv2d_nhwc_f16")
-        self._steps.append(run)
-        self._tunable.append((launch, state, f"{cin}->{cout} k{k}s{stride} {h}x{w}"))
-        return (h - 1) // stride + 1 if k == 3 else h // stride, (w - 1) // stride + 1 if k == 3 else w // stride
-
-    def _conv_upcat(self, mod, low: _View, skip: _View, dst: _View, h: int, w: int):
-        """1x1 convolution of cat([upsample2x(low), skip]) in one launch (rva_conv1x1_upcat_f16): neither the upsampled
-        tensor nor the concatenation exists in memory."""
-        conv = mod.conv if isinstance(mod, ConvBnAct) else mod
-        act = 1 if isinstance(mod, ConvBnAct) and mod.act else 0
-        wp, bp, cin, cout, k, stride = self._conv_params(conv)
-        assert k == 1 and stride == 1 and cin == low.ch + skip.ch and cout == dst.ch and cin % 32 == 0
-        B, L, ctx = self.B, self.L, self.ctx
-        state = {"variant": 0}
-
-        def launch(stream, variant):
-            if variant and not 33 <= variant <= 39:
-                return N.RVA_ERR_ARG
-            return L.rva_conv1x1_upcat_f16(ctx.handle, low.ptr, low.ld, low.ch, skip.ptr, skip.ld, skip.ch, _p(wp), _p(bp),
-                                           dst.ptr, dst.ld, B, h, w, cout, act, variant, stream)
-
-        def run(stream):
-            ctx.check(launch(stream, state["variant"]), "rva_conv1x1_upcat_f16")
-        self._steps.append(run)
-        self._tunable.append((launch, state, f"up{low.ch}+{skip.ch}->{cout} k1s1 {h}x{w}"))
-
-    def _conv_head(self, conv, src: _View, mode: int, h: int, w: int, a0: int, stride: float):
-        """Last 1x1 convolution of a detect-head branch with the head decode as its epilogue (rva_conv1x1_head_f16):
-        mode 1 = box branch, mode 2 = class branch; writes rows of ``self.out`` at anchor offset ``a0``."""
-        wp, bp, cin, cout, k, st = self._conv_params(conv)
-        assert k == 1 and st == 1 and cin == src.ch
-        B, L, ctx = self.B, self.L, self.ctx
-        state = {"variant": 0}
-
-        def launch(stream, variant):
-            if variant and not 33 <= variant <= 39:
-                return N.RVA_ERR_ARG
-            return L.rva_conv1x1_head_f16(ctx.handle, src.ptr, src.ld, _p(wp), _p(bp), B, h, w, cin, cout, mode, _p(self.out), self.nc,
-                                          self.A, a0, C.c_float(stride), variant, stream)
-
-        def run(stream):
-            ctx.check(launch(stream, state["variant"]), "rva_conv1x1_head_f16")
-        self._steps.append(run)
-        self._tunable.append((launch, state, f"head{mode}:{cin}->{cout} k1s1 {h}x{w}"))
-
-    def _c2f(self, mod: C2f, src, dst: _View, h: int, w: int):
-        """``src``: a view, or a pair (low, skip) standing for cat([upsample2x(low), skip])."""
-        c, n = mod.c, len(mod.m)
-        m = self.B * h * w
-        cat = _View(self._buf(m, (2 + n) * c), 0, (2 + n) * c)
-        if isinstance(src, tuple):
-            self._conv_upcat(mod.cv1, src[0], src[1], cat.sub(0, 2 * c), h, w)
-        else:
-            self._conv(mod.cv1, src, cat.sub(0, 2 * c), h, w)
-        tmp = _View(self._buf(m, c), 0, c)
-        for i, b in enumerate(mod.m):
-            x = cat.sub((1 + i) * c, c)
-            self._conv(b.cv1, x, tmp, h, w)
-            self._conv(b.cv2, tmp, cat.sub((2 + i) * c, c), h, w, res=x if b.add else None)
-        self._conv(mod.cv2, cat, dst, h, w)
-
-    def _sppf(self, mod: SPPF, src: _View, dst: _View, h: int, w: int):
-        c_ = mod.cv1.conv.out_channels
-        m = self.B * h * w
-        cat = _View(self._buf(m, 4 * c_), 0, 4 * c_)
-        self._conv(mod.cv1, src, cat.sub(0, c_), h, w)
-        B, L, ctx = self.B, self.L, self.ctx
-        if h * w <= 2400:            # the three chained pools as one launch (pool9 / pool13 of the same LDS tile)
-            x, y1, y2, y3 = (cat.sub(i * c_, c_) for i in range(4))
-
-            def run3(stream):
-                ctx.check(L.rva_sppf_pool3_nhwc_f16(ctx.handle, x.ptr, x.ld, y1.ptr, y2.ptr, y3.ptr, y1.ld, B, h, w, c_, stream),
-                          "sppf_pool3")
-            self._steps.append(run3)
-        else:
-            for i in range(3):
-                s, d = cat.sub(i * c_, c_), cat.sub((i + 1) * c_, c_)
-
-                def run(stream, s=s, d=d):
-                    ctx.check(L.rva_maxpool5_nhwc_f16(ctx.handle, s.ptr, s.ld, d.ptr, d.ld, B, h, w, c_, stream), "maxpool5")
-                self._steps.append(run)
-        self._conv(mod.cv2, cat, dst, h, w)
-
-    def _upsample(self, src: _View, dst: _View, h: int, w: int):
-        B, L, ctx = self.B, self.L, self.ctx
-
-        def run(stream):
-            ctx.check(L.rva_upsample2x_nhwc_f16(ctx.handle, src.ptr, src.ld, dst.ptr, dst.ld, B, h, w, src.ch, stream), "upsample")
-        self._steps.append(run)
-
-    def _set_lane(self, lane: int) -> None:
-        """Steps appended from now on run on side stream ``lane`` (0 = main).  A side lane forks off the main stream at the
-        point of this call (everything appended before it on the main lane is its dependency) and joins at the end."""
-        self._lane_of += [self._lane] * (len(self._steps) - len(self._lane_of))
-        self._lane = lane
-
-    # -- the graph ------------------------------------------------------------------------------------
-    def _build(self, net: YoloV8):
-        B, H, W = self.B, self.H, self.W
-        c1 = net.b0.conv.out_channels; c2 = net.b1.conv.out_channels; c3 = net.b3.conv.out_channels
-        c4 = net.b5.conv.out_channels; c5 = net.b7.conv.out_channels
-        h1, w1, h2, w2 = H // 2, W // 2, H // 4, W // 4
-        h3, w3, h4, w4, h5, w5 = H // 8, W // 8, H // 16, W // 16, H // 32, W // 32
-        # stem (planar input from K1)
-        sw = torch.zeros((64, 32), dtype=torch.float16)
-        w0 = net.b0.conv.weight.detach().float().cpu().reshape(c1, 9, 3)        # [co][j = c*3+ky][kx]
-        sw[:c1, 0:18] = w0[:, :, 0:2].reshape(c1, 18).half()                     # k = 2*j + kx, kx in {0,1}
-        sw[:c1, 18:27] = w0[:, :, 2].half()                                      # k = 18 + j, kx = 2
-        sb = torch.zeros((64,), dtype=torch.float32)
-        sb[:c1] = net.b0.conv.bias.detach().float().cpu()
-        sw, sb = sw.to(self.dev), sb.to(self.dev)
-        self._keep += [sw, sb]
-        L, ctx = self.L, self.ctx
-        self._in_ptr = None
-        x1 = _View(self._buf(B * h2 * w2, c2), 0, c2)
-        import os
-        self.fused_stem = (c1, c2) == (32, 64) and isinstance(net.b1, ConvBnAct) and net.b1.act \
-            and os.environ.get("RVA_NO_STEM2", "0") != "1"
-        if self.fused_stem:
-            # YOLOv8s widths: stem + first downsampling convolution in one launch, the 32-channel half-resolution tensor
-            # (210 MB at batch 32) stays in LDS
-            wp1, bp1, _, _, _, _ = self._conv_params([net.b1.conv])
-
-            def stem2(stream):
-                ctx.check(L.rva_stem2_f16(ctx.handle, self._in_ptr, _p(sw), _p(sb), _p(wp1), _p(bp1),
-                                          x1.ptr, x1.ld, B, H, W, stream), "stem2")
-            self._steps.append(stem2)
-        else:
-            x0 = _View(self._buf(B * h1 * w1, c1), 0, c1)
-
-            def stem(stream):
-                ctx.check(L.rva_stem_conv_f16(ctx.handle, self._in_ptr, _p(sw), _p(sb),
-                                              x0.ptr, x0.ld, B, H, W, c1, stream), "stem")
-            self._steps.append(stem)
-            self._conv(net.b1, x0, x1, h1, w1)
-        x2 = _View(self._buf(B * h2 * w2, c2), 0, c2)
-        self._c2f(net.b2, x1, x2, h2, w2)
-        # concat buffers of the neck: producers write their slice directly
-        cat15 = _View(self._buf(B * h3 * w3, c4 + c3), 0, c4 + c3)     # [up(n4) | p3]
-        cat12 = _View(self._buf(B * h4 * w4, c5 + c4), 0, c5 + c4)     # [up(p5) | p4]
-        cat18 = _View(self._buf(B * h4 * w4, c3 + c4), 0, c3 + c4)     # [h16(n3) | n4]
-        cat21 = _View(self._buf(B * h5 * w5, c4 + c5), 0, c4 + c5)     # [h19(m4) | p5]
-        p3, p4, n4, p5 = cat15.sub(c4, c3), cat12.sub(c5, c4), cat18.sub(c3, c4), cat21.sub(c4, c5)
-        t3 = _View(self._buf(B * h3 * w3, c3), 0, c3)
-        self._conv(net.b3, x2, t3, h2, w2)
-        self._c2f(net.b4, t3, p3, h3, w3)
-        t4 = _View(self._buf(B * h4 * w4, c4), 0, c4)
-        self._conv(net.b5, p3, t4, h3, w3)
-        self._c2f(net.b6, t4, p4, h4, w4)
-        t5 = _View(self._buf(B * h5 * w5, c5), 0, c5)
-        # from here on the backbone works at 20x20 (b7, b8, SPPF): a quarter of a millisecond in which most CUs and most of
-        # the HBM bandwidth are idle -- a pipelined runner may start the NEXT tick's K1 here (``phase_event``)
-        self.quiet_step = len(self._steps)
-        self._conv(net.b7, p4, t5, h4, w4)
-        t5b = _View(self._buf(B * h5 * w5, c5), 0, c5)
-        self._c2f(net.b8, t5, t5b, h5, w5)
-        self._sppf(net.b9, t5b, p5, h5, w5)
-        fuse_up = c5 % 64 == 0 and c4 % 64 == 0 and c3 % 64 == 0 and h4 == 2 * h5 and w4 == 2 * w5 and h3 == 2 * h4 and w3 == 2 * w4
-        n3 = _View(self._buf(B * h3 * w3, c3), 0, c3)
-        if fuse_up:      # FPN top-down path: upsample + concat folded into the consuming 1x1 convolutions
-            self._c2f(net.h12, (p5, p4), n4, h4, w4)
-            self._c2f(net.h15, (n4, p3), n3, h3, w3)
-        else:
-            self._upsample(p5, cat12.sub(0, c5), h5, w5)
-            self._c2f(net.h12, cat12, n4, h4, w4)
-            self._upsample(n4, cat15.sub(0, c4), h4, w4)
-            self._c2f(net.h15, cat15, n3, h3, w3)
-        fork_n3 = len(self._steps)                    # n3 is complete here: the stride-8 detect branch may start
-        self._conv(net.h16, n3, cat18.sub(0, c3), h3, w3)
-        m4 = _View(self._buf(B * h4 * w4, c4), 0, c4)
-        self._c2f(net.h18, cat18, m4, h4, w4)
-        fork_m4 = len(self._steps)                    # m4 is complete: the stride-16 detect branch may start
-        self._conv(net.h19, m4, cat21.sub(0, c4), h4, w4)
-        m5 = _View(self._buf(B * h5 * w5, c5), 0, c5)
-        self._c2f(net.h21, cat21, m5, h5, w5)
-        # detect head
-        A = h3 * w3 + h4 * w4 + h5 * w5
-        self.A = A
-        self.out = torch.empty((B, 4 + self.nc, A), dtype=torch.float16, device=self.dev)
-        a0 = 0
-        levels = []
-        # the last 1x1 convolution of each branch can decode straight into the result tensor (no logits in HBM, no head
-        # kernel) when its input width suits the LDS-DMA gather kernel
-        fuse_head = all(net.detect.box[l][2].in_channels % 64 == 0 and net.detect.cls[l][2].in_channels % 64 == 0 and
-                        net.detect.box[l][2].out_channels == 64 and net.detect.cls[l][2].out_channels == self.nc for l in range(3))
-        for lvl, (feat, hh, ww, stride) in enumerate(((n3, h3, w3, 8.0), (m4, h4, w4, 16.0), (m5, h5, w5, 32.0))):
-            # The three detect branches only depend on their own feature map and write disjoint anchor ranges of the
-            # result: the stride-8 branch (the big one) runs on a side stream beside the rest of the neck -- h16 ... h21
-            # are 40x40 / 20x20 layers that leave most CUs idle -- and the stride-16 branch beside h19 / h21; they join
-            # the main stream at the end of the plan.  Only when the decode is fused into the branches (no k_head3).
-            primary = lvl + 1 if (fuse_head and lvl < 2) else 0
-            self._set_lane(primary)
-            if primary:
-                self._forks[primary] = (0, fork_n3 if lvl == 0 else fork_m4)
-            box, cls = net.detect.box[lvl], net.detect.cls[lvl]
-            m = B * hh * ww
-            cb = box[0].conv.out_channels
-            cc = cls[0].conv.out_channels
-            # the first convolution of the box and of the class branch read the same feature map: one launch with
-            # Cout = cb + cc writing one buffer, the branches continue on its channel slices
-            first = _View(self._buf(m, cb + cc), 0, cb + cc)
-            b1, k1 = first.sub(0, cb), first.sub(cb, cc)
-            b2 = _View(self._buf(m, cb), 0, cb)
-            bo = _View(self._buf(m, 64), 0, 64)
-            k2 = _View(self._buf(m, cc), 0, cc)
-            ko = _View(self._buf(m, self.nc), 0, self.nc)
-            self._conv([box[0], cls[0]], feat, first, hh, ww)
-            if fuse_head:
-                # box and class sub-branches are independent after the shared first convolution: the class one gets a
-                # lane of its own
-                fork_cls = len(self._steps)
-                self._conv(box[1], b1, b2, hh, ww); self._conv_head(box[2], b2, 1, hh, ww, a0, stride)
-                if self._split_branches:
-                    self._set_lane(4 + lvl)
-                    self._forks[4 + lvl] = (primary, fork_cls)
-                self._conv(cls[1], k1, k2, hh, ww); self._conv_head(cls[2], k2, 2, hh, ww, a0, stride)
-                self._set_lane(primary)
-            else:
-                self._conv(box[1], b1, b2, hh, ww); self._conv(box[2], b2, bo, hh, ww)
-                self._conv(cls[1], k1, k2, hh, ww); self._conv(cls[2], k2, ko, hh, ww)
-            levels.append((bo, ko, hh, ww, stride))
-            a0 += hh * ww
-        self._set_lane(0)
-        if fuse_head:
-            return
-        # DFL + dist2bbox + sigmoid of the three levels in one launch
-        bp, _k1 = N.ptr_array([lv[0].ptr.value for lv in levels]); kp, _k2 = N.ptr_array([lv[1].ptr.value for lv in levels])
-        lb, _k3 = N.i32_array([lv[0].ld for lv in levels]); lc, _k4 = N.i32_array([lv[1].ld for lv in levels])
-        hs, _k5 = N.i32_array([lv[2] for lv in levels]); ws, _k6 = N.i32_array([lv[3] for lv in levels])
-        st = (C.c_float * 3)(*[lv[4] for lv in levels])
-        self._keep += [_k1, _k2, _k3, _k4, _k5, _k6, st]
-        B_, nc = B, self.nc
-
-        def head(stream):
-            ctx.check(L.rva_yolo_head3_f16(ctx.handle, bp, lb, kp, lc, _p(self.out), B_, hs, ws, nc, A, st, stream), "yolo_head3")
-        self._steps.append(head)
+    def __del__(self):  # best effort
+        try:
+            if getattr(self, "handle", None):
+                self.L.rva_yolov8_plan_destroy(self.handle)
+                self.handle = None
+        except Exception:  # noqa: BLE001
+            pass
 
     # -- per-layer kernel selection ---------------------------------------------------------------------
     # -- persisted kernel selection -----------------------------------------------------------------------
@@ -596,52 +363,32 @@ class FusedYoloV8:
 
     # -- run ------------------------------------------------------------------------------------------
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
-        """``x``: fp16 planar ``[B,3,H,W]`` contiguous (what K1 writes).  Returns ``[B, 4+nc, A]`` fp16."""
+        """``x``: fp16 planar ``[B,3,H,W]`` contiguous (what K1 writes).  Returns ``[B, 4+nc, A]`` fp16.  One ABI call."""
         assert x.is_cuda and x.dtype == torch.float16 and x.is_contiguous() and tuple(x.shape) == (self.B, 3, self.H, self.W)
-        self._in_ptr = C.c_void_p(x.data_ptr())
         main = torch.cuda.current_stream()
         stream = C.c_void_p(main.cuda_stream)
-        if not (self.concurrent_heads and self._forks):
-            ev = getattr(self, "phase_event", None)
-            for i, step in enumerate(self._steps):
-                if ev is not None and i == self.quiet_step:
-                    ev.record(main)                        # the pass enters its 20x20 phase
-                step(stream)
+        xin, out = C.c_void_p(x.data_ptr()), C.c_void_p(self.out.data_ptr())
+        if self.concurrent_heads and self._forks:
+            # fork / join over events inside the plan: works eagerly and inside a stream capture
+            if self._side is None:
+                self._side = (torch.cuda.Stream(device=self.dev), torch.cuda.Stream(device=self.dev))
+            self.ctx.check(self.L.rva_yolov8_plan_run_lanes(self.handle, xin, out, stream, C.c_void_p(self._side[0].cuda_stream),
+                                                            C.c_void_p(self._side[1].cuda_stream)), "rva_yolov8_plan_run_lanes")
             return self.out
-        # fork / join over events: works eagerly and inside a stream capture (the side streams join the capture through
-        # the fork events and leave it through the join events)
-        for lane in self._forks:
-            if lane not in self._side:
-                self._side[lane] = (torch.cuda.Stream(device=self.dev), torch.cuda.Event(), torch.cuda.Event())
-        started = set()
-
-        def stream_of(lane):
-            return main if lane == 0 else self._side[lane][0]
-        for i, step in enumerate(self._steps):
-            for lane, (parent, pt) in self._forks.items():
-                if pt == i:
-                    self._side[lane][1].record(stream_of(parent))  # everything the parent lane has been given so far is done
-            lane = self._lane_of[i]
-            if lane == 0:
-                step(stream)
-            else:
-                side, fork_ev, _ = self._side[lane]
-                if lane not in started:
-                    side.wait_event(fork_ev)
-                    started.add(lane)
-                step(C.c_void_p(side.cuda_stream))
-        for lane in started:
-            side, _, join_ev = self._side[lane]
-            join_ev.record(side)
-            main.wait_event(join_ev)
+        ev = getattr(self, "phase_event", None)
+        if ev is not None:
+            self.ctx.check(self.L.rva_yolov8_plan_run_range(self.handle, xin, out, 0, self.quiet_step, stream), "rva_yolov8_plan_run_range")
+            ev.record(main)                                # the pass enters its 20x20 phase
+            self.ctx.check(self.L.rva_yolov8_plan_run_range(self.handle, xin, out, self.quiet_step, self._n_steps, stream),
+                           "rva_yolov8_plan_run_range")
+        else:
+            self.ctx.check(self.L.rva_yolov8_plan_run(self.handle, xin, out, stream), "rva_yolov8_plan_run")
         return self.out
 
     def use_output(self, index: int) -> torch.Tensor:
         """Select which result tensor the head kernels write (``index`` 0 is the one allocated at construction, others are
         allocated on first use).  A pipelined caller alternates two per tick (and uses a pair per frame group), so the
         post-process of tick k can still read its head tensor on another HIP stream while the network of tick k+1 runs."""
-        if not hasattr(self, "_outs"):
-            self._outs = {0: self.out}
         if index not in self._outs:
             self._outs[index] = torch.empty_like(self._outs[0])
         self.out = self._outs[index]
@@ -649,4 +396,4 @@ class FusedYoloV8:
 
     @property
     def n_launches(self) -> int:
-        return len(self._steps)
+        return self._n_steps

@@ -422,6 +422,9 @@ class PipelinedTicks:
         # 17.2 k vs 16.0 k frames/s); ~75 launches per tick cost the host ~0.3 ms of a 1.9 ms tick.  The latency-bound
         # tail on stream B (K2/K3 -> K4 -> ids -> snapshot) is what the captured graph is for.
         self.net_graph = bool(net_graph) and self.use_graph
+        # with net_graph the network of a captured tick shape exists both ways; `replay_net` picks per tick (a caller may time both:
+        # the graph saves ~0.35 ms of host time per tick and costs the GPU 2-5 % -- it wins where the host is the limit, YOLOv8n x 4)
+        self.replay_net = self.net_graph
         # ``overlap=False`` keeps everything on one stream (eager only): the per-stage timing pass of bench.py
         self.two_streams = (overlap or self.use_graph) and chains_ok         # needs per-parity result buffers
         self.sA = torch.cuda.current_stream()
@@ -620,7 +623,7 @@ class PipelinedTicks:
                 if self.two_streams and gi == 0 and k >= self.nslots:
                     sa.wait_event(self._done[par])                 # the slot's previous tick has finished reading its head tensors
                 pres.append(pre)
-                if replay and self.net_graph:
+                if replay and self.net_graph and self.replay_net:
                     self._net_graphs[gi][par].replay()
                 else:
                     with torch.inference_mode():
