@@ -78,12 +78,12 @@ def parse():
                          "both are timed during warm-up and the faster one runs the timed region (the graph wins where the host is "
                          "the limit: YOLOv8n x 4 streams)")
     ap.add_argument("--depth", type=int, default=None, choices=[1, 2, 3, 4, 5, 6, 7, 8],
-                    help="ticks in flight, each a chain on its own HIP stream: 3 (default) measured +3..7 %% frames/s over 2 at "
+                    help="ticks in flight, each a chain on its own HIP stream: 3 (default on one GPU) measured +3..7 %% frames/s over 2 at "
                          "+1.6 ms p99 latency; the runtime has four hardware lanes for streams, so a fourth chain shares one with the "
-                         "default stream and is slower than two; 1 = strictly synchronous ticks (lowest latency).  Default 3, also with "
-                         "sharded streams: this torch launches a synchronous collective on the CURRENT stream, so the id all-gather brings "
-                         "no stream of its own (a fifth stream would cost three chains 15 %%: profiles/r03_experiments_not_kept.txt #14 "
-                         "-- use --depth 2 if a SCALE record shows per-rank rates well under the single-GPU figure)")
+                         "default stream and is slower than two; 1 = strictly synchronous ticks (lowest latency).  With sharded streams "
+                         "(--gpus N > 1) the default is 2: a collective on a stream of its own would be a fifth stream (measured with a "
+                         "stand-in: -15 %% with three chains, 0 %% with two, profiles/r03_experiments_not_kept.txt #14) and no 8-GPU record "
+                         "shows yet where RCCL puts it -- pass --depth 3 to compare")
     return ap.parse_args()
 
 
@@ -133,9 +133,25 @@ def spawn_ranks(args) -> int:
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *sys.argv[1:]], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0)
+    # wait for all ranks; when one dies the others leave through the failure path of the id exchange (dist.fail: non-zero exit
+    # within RVA_DIST_TIMEOUT_S) -- a rank still alive well after that is killed by its exact pid, never left hanging
+    import threading
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    first_exit = None
+    grace = float(os.environ.get("RVA_DIST_TIMEOUT_S", "60")) + 30.0
+    while any(p.poll() is None for p in procs):
+        if first_exit is None and any(p.poll() not in (None, 0) for p in procs):
+            first_exit = time.monotonic()
+        if first_exit is not None and time.monotonic() - first_exit > grace:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+        time.sleep(0.05)
+    reader.join(timeout=10)
+    codes = [p.returncode for p in procs]
+    sys.stdout.write(out0[0] if out0 else "")
     sys.stdout.flush()
     bad = [(r, c) for r, c in enumerate(codes) if c != 0]
     if bad:
@@ -153,7 +169,7 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"bench.py: WORLD_SIZE={world} from the launcher but --gpus {args.gpus}; they must agree")
     if args.depth is None:
-        args.depth = 3
+        args.depth = 3 if world == 1 else 2        # sharded default: two chains until a SCALE record shows where RCCL puts its collective (--depth 3 to compare)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP hot path has no CPU fallback")
     if os.environ.get("RVA_SHARE_GPU") != "1" and torch.cuda.device_count() <= local:
@@ -342,6 +358,7 @@ def main():
         torch.distributed.all_gather(allr, mine)
         allr = torch.stack(allr).cpu().numpy()
         multi = {"ranks_seen": int(torch.distributed.get_world_size()), "backend": str(torch.distributed.get_backend()),
+                 "ticks_in_flight": runner.depth,
                  "devices_visible": int(torch.cuda.device_count()), "shared_gpu_rehearsal": os.environ.get("RVA_SHARE_GPU") == "1",
                  "per_rank_frames_per_s": {"min": round(float(allr[:, 0].min()), 1), "max": round(float(allr[:, 0].max()), 1)},
                  "id_exchange_us_per_tick": {"mean": round(float(allr[:, 1].mean()), 1), "max_over_ranks": round(float(allr[:, 2].max()), 1),

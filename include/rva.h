@@ -167,6 +167,9 @@ int rva_post_status(rva_ctx *ctx, rva_stream_t stream, int *flags);
  * wavefront per stream; the per-detection greedy loop of tracker.py:55-92 stays sequential inside
  * it), then rva_tracker_assign_ids() hands out the reference's GLOBAL ids (tracker.py:47) in the
  * canonical order "stream-minor within the tick".
+ * Memory: 64 B per table row (n_streams x capacity rows) + eight pinned, device-mapped snapshot slots of the same size + the
+ * float64 IoU matrix of the busy-scene form, n_streams x min(capacity, 512) x (capacity + 512) doubles capped at 512 MiB
+ * (201 MB at 32 streams x capacity 1024); if that matrix cannot be allocated the tracker runs the in-loop form (same results).
  * -------------------------------------------------------------------------------------------- */
 int rva_tracker_create(rva_ctx *ctx, int n_streams, int capacity, int max_age, double max_iou_distance,
                        int min_hits, rva_tracker **out);

@@ -6,6 +6,7 @@ cpu_baseline leg -- never by the product package.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import subprocess
 from pathlib import Path
 from typing import Optional, Sequence
@@ -17,10 +18,13 @@ _LIB: Optional[C.CDLL] = None
 
 
 def build(force: bool = False) -> Path:
-    so = _HERE / "liborc.so"
+    """liborc.so, or -- RVA_ORACLE_LIB=liborc_asan.so, with libasan / libubsan preloaded -- the AddressSanitizer + UBSan build
+    of the same source (``make asan``; tests/test_oracle_golden.py replays the goldens under it in a child process)."""
+    name = os.environ.get("RVA_ORACLE_LIB", "liborc.so")
+    so = _HERE / name
     src = _HERE / "rva_oracle.c"
     if force or not so.exists() or (src.exists() and so.stat().st_mtime < src.stat().st_mtime):
-        subprocess.check_call(["make", "-s", "-C", str(_HERE), "liborc.so"])
+        subprocess.check_call(["make", "-s", "-C", str(_HERE), "asan" if name == "liborc_asan.so" else "liborc.so"])
     return so
 
 

@@ -579,9 +579,17 @@ int rva_tracker_create(rva_ctx *ctx, int n_streams, int capacity, int max_age, d
         RVA_HIP(ctx, hipMemcpy(t->d_bscale, ones.data(), n_streams * 8, hipMemcpyHostToDevice));
     }
     if (dm > 0) {
-        RVA_HIP(ctx, hipMalloc(&t->d_V, (size_t)n_streams * dm * ld * sizeof(double)));
-        RVA_HIP(ctx, hipMalloc(&t->d_A, (size_t)n_streams * dm * sizeof(int32_t)));
-        t->dm = dm; t->ld = ld;
+        // the IoU matrix of the busy-scene form (k4_iou): n_streams x dm x ld doubles, up to 512 MiB (32 streams x capacity 1024:
+        // 201 MB).  It is an accelerator, not a requirement: when HBM cannot give it, the tracker keeps the in-loop form (dm = 0,
+        // same results) instead of failing the creation.
+        if (hipMalloc(&t->d_V, (size_t)n_streams * dm * ld * sizeof(double)) == hipSuccess &&
+            hipMalloc(&t->d_A, (size_t)n_streams * dm * sizeof(int32_t)) == hipSuccess) {
+            t->dm = dm; t->ld = ld;
+        } else {
+            (void)hipGetLastError();                       // clear the sticky allocation error
+            if (t->d_V) { (void)hipFree(t->d_V); t->d_V = nullptr; }
+            t->d_A = nullptr; t->dm = 0; t->ld = 0;
+        }
     }
     RVA_HIP(ctx, hipMalloc(&t->gate_cfg, n_streams * 16));
     RVA_HIP(ctx, hipMalloc(&t->gate_state, n_streams * 16));

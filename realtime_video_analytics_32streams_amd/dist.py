@@ -50,15 +50,15 @@ def fail(why: str) -> None:
 def wait_event(event, what: str = "tick", deadline_s: Optional[float] = None) -> None:
     """Host wait for a HIP event of a sharded tick, bounded: a collective whose peer died never completes, and
     ``event.synchronize()`` would then block for ever.  Polls; on expiry -> ``fail``."""
-    limit = time.monotonic() + (timeout_s() + 5.0 if deadline_s is None else deadline_s)
+    budget = timeout_s() + 5.0 if deadline_s is None else deadline_s
+    limit = time.monotonic() + budget
     spins = 0
     while not event.query():
         spins += 1
         if spins > 2000:                      # the common case (a tick takes milliseconds) never sleeps
             time.sleep(2e-4)
         if time.monotonic() > limit:
-            fail(f"{what} did not complete within {limit - time.monotonic() + (timeout_s() + 5.0 if deadline_s is None else deadline_s):.0f} s "
-                 "(a peer of the id exchange is gone or stuck)")
+            fail(f"{what} did not complete within {budget:.0f} s (a peer of the id exchange is gone or stuck)")
 
 
 def init_from_env(backend: Optional[str] = None) -> tuple[int, int, int]:

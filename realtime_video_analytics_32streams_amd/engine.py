@@ -176,8 +176,13 @@ class FusedYoloV8:
                 return False
         except (OSError, ValueError, KeyError, TypeError):
             return False
-        for (_, state, _), (_, v) in zip(self._tunable, picks):
-            state["variant"] = int(v)
+        try:
+            for (_, state, _), (_, v) in zip(self._tunable, picks):
+                state["variant"] = int(v)          # the plan checks the variant number against this build (a stale or edited file)
+        except RuntimeError:
+            for _, state, _ in self._tunable:
+                state["variant"] = 0
+            return False
         self.tuning = [tuple(t) for t in rec.get("tuning", [])]
         self.tuning_source = str(f)
         return True

@@ -28,6 +28,54 @@ def chain_streams(device, n: int) -> list:
     return lst[:n]
 
 
+class _Roctx:
+    """roctx ranges around the stages of a tick (tracing), behind ``RVA_ROCTX=1``: K1, network, tail of every
+    tick show up as named host ranges in a ``rocprofv3 --marker-trace`` timeline.  Off by default (two library calls per
+    stage); a missing ``libroctx64.so`` switches it off silently -- it is a tracing aid, not part of the hot path."""
+
+    def __init__(self):
+        import os
+        self.lib = None
+        if os.environ.get("RVA_ROCTX") == "1":
+            for name in ("librocprofiler-sdk-roctx.so", "libroctx64.so"):
+                try:
+                    self.lib = C.CDLL(name)
+                    self.lib.roctxRangePushA.argtypes = [C.c_char_p]
+                    break
+                except (OSError, AttributeError):
+                    self.lib = None
+
+    def range(self, name: str):
+        return _RoctxRange(self.lib, name)
+
+
+class _RoctxRange:
+    __slots__ = ("lib", "name")
+
+    def __init__(self, lib, name):
+        self.lib, self.name = lib, name
+
+    def __enter__(self):
+        if self.lib is not None:
+            self.lib.roctxRangePushA(self.name.encode())
+        return self
+
+    def __exit__(self, *exc):
+        if self.lib is not None:
+            self.lib.roctxRangePop()
+        return False
+
+
+_ROCTX: Optional[_Roctx] = None
+
+
+def roctx(name: str) -> _RoctxRange:
+    global _ROCTX
+    if _ROCTX is None:
+        _ROCTX = _Roctx()
+    return _ROCTX.range(name)
+
+
 def _stream_ptr() -> C.c_void_p:
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 

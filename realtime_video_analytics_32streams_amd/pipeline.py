@@ -124,6 +124,17 @@ class TickPipeline:
         self._motion: Optional[MotionGate] = None
         self._motion_on = [bool(s.motion_filter) for s in self.streams]
         self.has_gates = any(self._motion_on) or any(a.enabled for a in self.adaptive)
+        # Streams with a gate (adaptive fps / motion) on a STATEFUL head: the reference never shows a skipped frame to the detector
+        # (pipeline.py:156-181), so its clip buffer holds processed frames only.  Device-decided gates run every delivered frame
+        # through stage_pre -- harmless for the stateless YOLO head, wrong for a clip ring -- so that combination keeps the gates
+        # on the host (TickPipeline.tick) and is refused by the device-gate modes.
+        self.gated_stateful = [self.names[i] for i in range(len(self.streams))
+                               if (self._motion_on[i] or self.adaptive[i].enabled) and getattr(self.detectors[self.det_of[i]], "two_chain_ok", False)]
+        # the temporal heads size their frame ring for all their streams now (a ring that grows mid-run would be swapped under
+        # ticks still in flight on other streams)
+        for j, d in enumerate(self.detectors):
+            if hasattr(d, "reserve_streams"):
+                d.reserve_streams([self.names[i] for i in range(len(self.streams)) if self.det_of[i] == j])
         self._gates_uploaded: Optional[tuple] = None
         self._roi_masks: Dict[int, torch.Tensor] = {}          # stream index -> device mask (built at the first frame)
         self.ratios = [float(s.downsample_ratio) for s in self.streams]
@@ -348,6 +359,9 @@ class TickPipeline:
         the detector; same decisions, and bit-identical detector batches with the pipelined mode).  Use one of the two
         modes for the life of a pipeline: each keeps its own adaptive-fps state."""
         t0 = time.perf_counter()
+        if device_gates and self.gated_stateful:
+            raise NotImplementedError(f"device-decided gates on temporal streams {self.gated_stateful}: a skipped frame must not enter "
+                                      "the clip buffer (pipeline.py:156-181); use tick() with host-decided gates for them")
         packets = self._frames_for_detection([src.next_packet() for src in self.sources])
         if process is None and self.has_gates and not device_gates:
             process = self._gate(packets)
@@ -398,12 +412,17 @@ class PipelinedTicks:
         if any(not hasattr(d, "stage_pre") for d in pipe.detectors):
             raise NotImplementedError("PipelinedTicks needs detectors with a batched device path (stage_pre / stage_net / "
                                       "stage_post); a host-only detector runs through TickPipeline.tick")
+        if pipe.gated_stateful:
+            raise NotImplementedError(f"PipelinedTicks decides gates on the device, after every delivered frame has been pre-processed: "
+                                      f"streams {pipe.gated_stateful} combine a gate (adaptive_fps / motion_filter) with a temporal head, "
+                                      "whose clip buffer must only see processed frames (pipeline.py:156-181) -- run them through "
+                                      "TickPipeline.tick() (host-decided gates)")
         if depth is None:
-            # three chains, also with sharded streams: torch >= 2.8 launches a synchronous collective (async_op=False, as IdSync
-            # issues it) on the CURRENT stream, so the id all-gather rides on the tick's own chain.  A collective on a stream of
-            # its own would be a fifth stream on a runtime with four stream lanes: -15 % with three chains, 0 % with two (measured
-            # with a stand-in on one GPU, profiles/r03_experiments_not_kept.txt #14) -- pass depth=2 on such a stack.
-            depth = 3
+            # Three chains on one GPU.  With sharded streams (pipe.id_sync) two: a collective that lands on a stream of its own
+            # would be a fifth stream on a runtime with four stream lanes -- measured with a stand-in on one GPU: -15 % with
+            # three chains, 0 % with two (profiles/r03_experiments_not_kept.txt #14) -- and no 8-GPU record exists yet that shows
+            # where RCCL puts it; `depth=3` stays available (and is held to the oracle by tests/test_gpu_multirank.py).
+            depth = 3 if pipe.id_sync is None else 2
         if depth not in range(1, 9):
             raise ValueError("depth must be 1 .. 8 (snapshot slots of the tracker, motion-count rows of the gate)")
         self.pipe, self.depth = pipe, depth
@@ -555,7 +574,7 @@ class PipelinedTicks:
     def _issue_post(self, k, after, stream=None):
         par, prev = k % self.nslots, (k - 1) % self.nslots
         sb = stream if stream is not None else self.sB
-        with torch.cuda.stream(sb):
+        with torch.cuda.stream(sb), ops.roctx(f"tick{k}:tail"):
             sb.wait_event(self._net_done[par])
             if stream is not None and k >= 1:
                 sb.wait_event(self._done[prev])                    # tails on several streams: tracker state is touched in tick order
@@ -614,7 +633,8 @@ class PipelinedTicks:
             with torch.cuda.stream(sk), torch.inference_mode():
                 if events and gi == 0: events[0].record()
                 if before_k1 and gi == 0: before_k1()
-                pre = det.stage_pre([packets[i] for i in g.idx])    # K1 (temporal heads: into the frame ring + clip schedule)
+                with ops.roctx(f"tick{k}:K1"):
+                    pre = det.stage_pre([packets[i] for i in g.idx])    # K1 (temporal heads: into the frame ring + clip schedule)
                 p._note_clips(g, getattr(pre, "infos", None))
                 if events and gi == 0: events[1].record()
                 if self.two_streams and gi == len(plan.groups) - 1:
@@ -633,7 +653,8 @@ class PipelinedTicks:
                             fp.phase_event = self._phase_ev[par] if (self.k1_gate and gi == 0) else None
                         elif plan_det:
                             self._plan_of(det, pre[0])             # sets the plan's branch mode for this runner's layout
-                        raws.append(det.stage_net(pre))
+                        with ops.roctx(f"tick{k}:network"):
+                            raws.append(det.stage_net(pre))
         with torch.cuda.stream(sa):
             if events: events[2].record()
             self._pending[par] = ("graph" if replay else "eager", plan, None if replay else raws, pres, motion,
@@ -677,7 +698,12 @@ class PipelinedTicks:
         if self.two_streams:
             if self._posted < k:
                 self._issue_post(k, None)                          # no younger tick was submitted: release the tail now
-            self._done[k % self.nslots].synchronize()
+            if self.world_sharded:
+                from . import dist as rdist
+                # a tick behind an id exchange whose peer died never completes: bounded wait, then a non-zero exit (dist.fail)
+                rdist.wait_event(self._done[k % self.nslots], what=f"tick {k} (id exchange of the sharded run)")
+            else:
+                self._done[k % self.nslots].synchronize()
             tables = self.dt.snapshot_fetch(k % self.nslots, wait=False)
         else:
             tables = self.dt.snapshot_fetch(k % self.nslots)       # tracks visible to the host

@@ -230,6 +230,11 @@ class _HipTemporalDetector:
             return (int(frame.width), int(frame.height), "nv12")
         return (int(frame.shape[1]), int(frame.shape[0]), "bgr")
 
+    def reserve_streams(self, names: Sequence[str]) -> None:
+        """Give every stream of the pipeline its ring column now (TickPipeline calls this once): the ring then never grows
+        while ticks are in flight."""
+        self._columns(list(names))
+
     def _columns(self, names: Sequence[str]) -> List[int]:
         new = [n for n in names if n not in self._col]
         if new:
@@ -238,9 +243,15 @@ class _HipTemporalDetector:
                 self._arrivals[n] = 0
                 self._bbuf[n] = deque()
             slots = self.sched.need + self.RING_EXTRA
+            if self._bring is not None:
+                # a stream nobody announced shows up mid-run: ticks in flight on other chain streams may still read the old
+                # ring, and the caching allocator could hand its block out again -- drain the device before the swap (rare,
+                # and never on the reserved path)
+                torch.cuda.synchronize(self.device)
             ring = torch.empty((slots, len(self._col), 3, *self.input_hw), dtype=self._frame_dtype(), device=self.device)
             if self._bring is not None:
                 ring[:, :self._bring.shape[1]] = self._bring
+                torch.cuda.synchronize(self.device)
             self._bring = ring
         return [self._col[n] for n in names]
 

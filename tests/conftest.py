@@ -10,6 +10,13 @@ if str(ROOT) not in sys.path:
 GOLDEN = ROOT / "tests" / "golden"
 
 
+# Kernel selections persisted by earlier runs must not decide what a test validates: every test session tunes into its own
+# directory (child processes inherit it).
+import os
+import tempfile
+os.environ.setdefault("RVA_TUNE_CACHE_DIR", tempfile.mkdtemp(prefix="rva_tune_"))
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -132,3 +132,30 @@ def assert_matches_rounded_reference(got16, want32, score_tol=2e-3, box_eps=0.03
     serr = (got[:, 4:] - w[:, 4:]).abs()
     assert float(serr.max()) < score_tol, ("scores", float(serr.max()))
     return float(berr.max()), float(serr.max())
+
+
+def fp16_error_report(tag, got16, want_fp32, matched, conf=0.25):
+    """What the fp16 plan costs in the units north_star speaks in: |dscore| and |dbox| in input pixels of
+    the plan's fp16 head tensor against (a) the plain fp32 module and (b) the rounding-matched reference -- max / mean / p99.9 --
+    and how many (anchor, class) threshold decisions at ``conf`` flip against (a).  Printed, returned and -- on the GPU box --
+    written to gpurun_out/fp16_error_<tag>.json so that the numbers land in DESIGN.md section 2, not only a bound in a test."""
+    import json
+    from pathlib import Path
+    import torch
+    got = got16.float()
+    rep = {"tag": tag, "anchors": int(got.shape[0] * got.shape[2]), "classes": int(got.shape[1] - 4), "conf": conf}
+    for name, ref in (("vs_fp32_module", want_fp32), ("vs_rounding_matched_reference", matched)):
+        r = ref.to(got.device).float()
+        ds = (got[:, 4:] - r[:, 4:]).abs().flatten()
+        db = (got[:, :4] - r[:, :4]).abs().flatten()
+        k_s, k_b = max(int(ds.numel() * 0.999), 1), max(int(db.numel() * 0.999), 1)
+        rep[name] = {"score": {"max": float(ds.max()), "mean": float(ds.mean()), "p99_9": float(ds.kthvalue(k_s).values)},
+                     "box_px": {"max": float(db.max()), "mean": float(db.mean()), "p99_9": float(db.kthvalue(k_b).values)}}
+        flips = ((got[:, 4:] >= conf) != (r[:, 4:] >= conf))
+        rep[name]["threshold_flips"] = {"count": int(flips.sum()), "of_decisions": int(flips.numel()),
+                                        "scores_at_or_above_conf_in_reference": int((r[:, 4:] >= conf).sum())}
+    print("fp16 error report:", json.dumps(rep))
+    out = Path(__file__).resolve().parents[1] / "gpurun_out"
+    if out.is_dir():
+        (out / f"fp16_error_{tag}.json").write_text(json.dumps(rep, indent=1))
+    return rep

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--total", type=int, default=8)
     ap.add_argument("--ticks", type=int, default=12)
     ap.add_argument("--target", type=int, default=60)
+    ap.add_argument("--depth", type=int, default=2)
     args = ap.parse_args()
     from realtime_video_analytics_32streams_amd import dist as rdist
     from realtime_video_analytics_32streams_amd import ops
@@ -64,14 +65,15 @@ def main():
     trk = IouTracker(tcfg, max_streams=S, capacity=1024, device=local)
     pipe = TickPipeline(streams, det, trk, sources=sources, id_sync=rdist.IdSync(S, dev) if world > 1 else None,
                         first_global_index=first, n_global_streams=args.total)
-    runner = PipelinedTicks(pipe, depth=2, use_graph=True)
+    runner = PipelinedTicks(pipe, depth=args.depth, use_graph=True)
     out = Path(args.out)
 
     def check(k):
         _, tables = runner.collect()
-        key = (S, 640, 640) if (runner.net_streams != 2 or k % 2 == 0) else (S, 640, 640, 1)
+        par = k % runner.nslots                                     # tick chains: every slot has its own plan, head tensor 0 of it
+        key = (S, 640, 640) if (runner.net_streams < 2 or par == 0) else (S, 640, 640, par)
         plan = det._plans[key]
-        head = (plan._outs[0] if runner.net_streams == 2 else plan._outs[k & 1]).cpu().numpy()      # tick k's head tensor (fp16)
+        head = (plan._outs[0] if runner.net_streams >= 2 else plan._outs[k & 1]).cpu().numpy()      # tick k's head tensor (fp16)
         rec = {"head": head}
         for s, t in enumerate(tables):
             n = int(t["n"])
@@ -80,13 +82,15 @@ def main():
                 rec[f"{f}{s}"] = np.asarray(t[f])[:n]
         np.savez(out / f"rank{rank}_tick{k:03d}.npz", **rec)
 
-    runner.submit()
-    for k in range(1, args.ticks):
+    done = 0
+    for k in range(args.ticks):                                    # `depth` ticks in flight; a tick's head tensor is intact until its
+        if k - done == runner.depth:                               # slot's next network runs, i.e. until `depth` further ticks are submitted
+            check(done); done += 1
         runner.submit()
-        check(k - 1)
-    check(args.ticks - 1)
+    while done < args.ticks:
+        check(done); done += 1
     torch.cuda.synchronize()
-    (out / f"rank{rank}.done").write_text(f"captured={runner._captured} net_streams={runner.net_streams} "
+    (out / f"rank{rank}.done").write_text(f"captured={runner._captured} net_streams={runner.net_streams} depth={runner.depth} "
                                           f"backend={torch.distributed.get_backend() if world > 1 else 'none'} world={world}\n")
     if world > 1:
         torch.distributed.barrier()

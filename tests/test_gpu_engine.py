@@ -12,7 +12,7 @@ from realtime_video_analytics_32streams_amd import _native as N
 from realtime_video_analytics_32streams_amd import ops
 from realtime_video_analytics_32streams_amd.engine import FusedYoloV8
 from realtime_video_analytics_32streams_amd.yolov8 import build_detector_net
-from tests.helpers import assert_matches_rounded_reference, plan_rounded_reference
+from tests.helpers import assert_matches_rounded_reference, fp16_error_report, plan_rounded_reference
 
 pytestmark = pytest.mark.gpu
 
@@ -229,7 +229,12 @@ def test_fused_plan_matches_torch_module(scale, batch):
     # ... and against the reference that rounds where the plan rounds (fp16 once per layer): a wiring error worth 1e-2 in a
     # score passes the loose bound above, not this one (north_star: coords and scores within 1e-3; the head tensor is fp16,
     # so a coordinate carries half an fp16 ulp of its own on top)
-    assert_matches_rounded_reference(eng(x), plan_rounded_reference(net, x))
+    matched = plan_rounded_reference(net, x)
+    assert_matches_rounded_reference(eng(x), matched)
+    rep = fp16_error_report(f"{scale}x{batch}", eng(x), want, matched)
+    # north_star's 1e-3 holds against the rounding-matched reference in the mean and at p99.9 of the scores; against the plain
+    # fp32 module it does NOT hold at the maximum (that is the fp16 network itself, not the kernels): stated in DESIGN.md section 2
+    assert rep["vs_rounding_matched_reference"]["score"]["p99_9"] < 1e-3 and rep["vs_fp32_module"]["score"]["mean"] < 1e-3
 
 
 @pytest.mark.parametrize("shape", [(2, 20, 20, 128, 64, 64), (1, 40, 24, 64, 128, 80), (3, 8, 10, 192, 64, 256)])
@@ -319,6 +324,8 @@ def test_fused_plan_at_bench_size_matches_torch_module():
     assert (got[:, :4] - want[:, :4]).abs().mean() < 0.2
     matched = torch.cat([plan_rounded_reference(net, x[i:i + 8]) for i in range(0, 32, 8)])
     assert_matches_rounded_reference(eng(x), matched)
+    rep = fp16_error_report("sx32", eng(x), want, matched)
+    assert rep["vs_rounding_matched_reference"]["score"]["p99_9"] < 1e-3 and rep["vs_fp32_module"]["score"]["mean"] < 1e-3
     # frames are independent: the plan gives the same answer for a frame wherever it sits in the batch
     y = eng(torch.roll(x, 5, 0)).float()
     assert torch.equal(torch.roll(y, -5, 0), got)

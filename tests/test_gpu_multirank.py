@@ -42,13 +42,15 @@ def test_bench_self_spawns_two_ranks_strong():
     assert "strong scaling" in j["config"]["workload"]
 
 
-def test_config3_yolov8m_sharded_ticks_give_the_oracles_tables_and_global_ids(tmp_path):
+@pytest.mark.parametrize("depth", [2, 3])
+def test_config3_yolov8m_sharded_ticks_give_the_oracles_tables_and_global_ids(tmp_path, depth):
     """BASELINE configs[3] in miniature: YOLOv8m, 8 x 1080p streams sharded 4 + 4 over two rank processes (device 0 shared,
     gloo), 12 ticks through ``PipelinedTicks`` with the per-tick all-gather of new-track counts.  Every rank dumps the head
     tensors its detector produced and the tables its host received (tests/sharded_worker.py); here ALL 8 streams go
     through the oracle's post-process and ONE oracle tracker (the reference's single shared ``IouTracker``,
     tracker.py:47, pipeline.py:452,502) in canonical order -- tick-major, stream-minor -- and every rank's tables must be
-    identical: ids out of the one global counter, age, hits, float64 boxes."""
+    identical: ids out of the one global counter, age, hits, float64 boxes.  Both with two tick chains (the sharded default) and
+    with three (``IdSync.buf`` shared by all slots, k4_assign_ids and the snapshot slot k mod 3 behind the graph replay)."""
     import socket
 
     import numpy as np
@@ -65,13 +67,13 @@ def test_config3_yolov8m_sharded_ticks_give_the_oracles_tables_and_global_ids(tm
         env = dict(base, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(WORLD), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    RVA_SHARE_GPU="1")
         procs.append(subprocess.Popen([sys.executable, str(ROOT / "tests" / "sharded_worker.py"), "--out", str(tmp_path), "--model", "m",
-                                       "--total", str(TOTAL), "--ticks", str(T)], env=env, stdout=subprocess.PIPE,
+                                       "--total", str(TOTAL), "--ticks", str(T), "--depth", str(depth)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=1100)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), [o[-3000:] for o in outs]
     for r in range(WORLD):
         done = (tmp_path / f"rank{r}.done").read_text()
-        assert "captured=True" in done and "backend=gloo" in done and f"world={WORLD}" in done, done
+        assert "captured=True" in done and "backend=gloo" in done and f"world={WORLD}" in done and f"depth={depth}" in done, done
     otr = orc.Tracker(TOTAL, 30, 0.5, 1)
     rows = new_ids = 0
     seen = set()

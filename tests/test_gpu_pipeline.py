@@ -350,3 +350,76 @@ def test_config4_shape_8x4k_cnn_lstm_clips_through_the_pipeline():
     assert last == {n: [(t_.track_id, t_.class_id, t_.action_label, t_.sequence_start_frame, t_.sequence_end_frame) for t_ in v]
                     for n, v in first.items()}
     assert all(np.allclose(conf2[n], [t_.confidence for t_ in first[n]], atol=1e-4) for n in first)
+
+
+def test_wire_bytes_from_a_device_snapshot_equal_the_track_object_path():
+    """Event wire format on real device output (/root/reference/src/realtime_analytics/sinks/kafka_sink.py:103-132):
+    the tables ``PipelinedTicks.collect()`` hands the host (pinned snapshot written by K4) turned into Kafka message bytes by
+    ``wire.payload_from_table`` -- no Track objects -- must be byte-identical to ``wire.tracks_payload`` on the Track objects
+    the tracker materialises from the same snapshot (what the reference's sink serialises), and parse back on the consumer side."""
+    from realtime_video_analytics_32streams_amd import wire
+    S, T = 4, 8
+    streams = [StreamConfig(name=f"cam{i}", url="synthetic://1920x1080", warmup_seconds=0.0) for i in range(S)]
+    srcs = [SyntheticNv12Stream(s, index=i, n_unique=3) for i, s in enumerate(streams)]
+    for s in srcs:
+        s.open_sync()
+    det = _calibrated("n", streams, srcs, 60)
+    trk = IouTracker(TrackerConfig(max_age=30, max_iou_distance=0.5, min_hits=1), max_streams=S, capacity=512)
+    pipe = TickPipeline(streams, det, trk, sources=srcs)
+    runner = PipelinedTicks(pipe, depth=3, use_graph=True)
+    msgs = tracks_seen = 0
+
+    def check(k):
+        nonlocal msgs, tracks_seen
+        _, tables = runner.collect()
+        for i, s in enumerate(streams):
+            tab = tables[pipe.slots[i]]
+            direct = wire.serialize(wire.payload_from_table(s.name, k, tab))
+            objs = trk.tracks_from_tables([s.name], [tab])[0]
+            via_tracks = wire.serialize(wire.tracks_payload(s.name, k, objs))
+            assert direct == via_tracks, (k, s.name)
+            ev = wire.parse_event(direct)
+            assert ev["stream"] == s.name and ev["frame_id"] == k and len(ev["tracks"]) == int(tab["n"])
+            assert [t["track_id"] for t in ev["tracks"]] == [int(v) for v in tab["id"][:int(tab["n"])]]
+            msgs += 1
+            tracks_seen += int(tab["n"])
+    for k in range(T):
+        if k >= runner.depth:
+            check(k - runner.depth)
+        runner.submit()
+    for k in range(max(T - runner.depth, 0), T):
+        check(k)
+    assert msgs == S * T and tracks_seen > S * T
+
+
+def test_gated_temporal_stream_keeps_its_gates_on_the_host():
+    """A gate (adaptive_fps / motion_filter) on a stream with a TEMPORAL head: the reference never shows a skipped frame to the
+    detector (pipeline.py:156-181), so its clip buffer holds processed frames only.  The device-gate modes pre-process every
+    delivered frame before the gate decides -- fine for the stateless YOLO head, a silent divergence for a clip ring -- and
+    therefore refuse the combination; ``tick()`` with host-decided gates runs it, and the clip schedule then sees exactly the
+    frames the gate let through."""
+    from realtime_video_analytics_32streams_amd.temporal import CnnLstmNet, HipCNNLSTMDetector
+    streams = [StreamConfig(name="clip", url="synthetic://640x360", warmup_seconds=0.0, target_fps=30.0, adaptive_fps=True,
+                            min_target_fps=10.0, idle_frame_tolerance=2),
+               StreamConfig(name="plain", url="synthetic://640x360", warmup_seconds=0.0)]
+    srcs = [SyntheticNv12Stream(s, index=i, width=640, height=360, n_unique=2) for i, s in enumerate(streams)]
+    for s in srcs:
+        s.open_sync()
+    dcfg = DetectorConfig(model_path="x.onnx", backend="hip", model_type="cnn_lstm", sequence_length=2, sequence_stride=1,
+                          temporal_overlap=0.5, confidence_threshold=1e9, num_action_classes=8, input_size=[64, 64], warmup=False)
+    torch.manual_seed(1)
+    det = HipCNNLSTMDetector(dcfg, net=CnnLstmNet(8, hidden=16))          # threshold 1e9: never emits -> the stream goes idle
+    trk = IouTracker(TrackerConfig(max_age=5, max_iou_distance=0.5, min_hits=1), max_streams=2, capacity=64)
+    pipe = TickPipeline(streams, det, trk, sources=srcs)
+    assert pipe.gated_stateful == ["clip"]
+    with pytest.raises(NotImplementedError, match="temporal"):
+        PipelinedTicks(pipe, depth=2)
+    with pytest.raises(NotImplementedError, match="temporal"):
+        pipe.tick(device_gates=True)
+    seen_before = det._arrivals.get("clip", 0)
+    processed = 0
+    for _ in range(12):
+        r = pipe.tick()                                                   # host-decided gates
+        processed += 1 if "clip" in r.detections_emitted else 0
+    arrivals = det._arrivals["clip"] - seen_before
+    assert 0 < arrivals < 12 and det._arrivals["plain"] == 12              # the idle stream was throttled; skipped frames never reached its ring

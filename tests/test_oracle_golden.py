@@ -176,3 +176,30 @@ def test_temporal_key_map_loads_a_reference_state_dict():
     assert any(k.startswith("cnn.") for k in ref_named) and any(k.startswith("lstm.") for k in ref_named)
     load_reference_state_dict(net, ref_named, "cnn_lstm")
     assert synth.state_sha(net.state_dict()) == synth.state_sha(ref_named, synth.TEMPORAL_KEY_MAP)
+
+
+def test_goldens_replay_clean_under_asan_and_ubsan():
+    """SURVEY.md section 5 (race / memory checking; sanitizers run on the CPU build only): the oracle built with
+    -fsanitize=address,undefined (oracle/Makefile target ``asan``) replays every golden case of this file in a child process
+    with the sanitizer runtimes preloaded; any report (heap overflow in the NMS scratch, signed overflow, misaligned load ...)
+    fails the test."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    libs = []
+    for name in ("libasan.so", "libubsan.so"):
+        p = subprocess.run(["gcc", f"-print-file-name={name}"], capture_output=True, text=True).stdout.strip()
+        if not p or not Path(p).is_file():
+            pytest.skip(f"{name} is not installed")
+        libs.append(str(Path(p).resolve()))
+    subprocess.check_call(["make", "-s", "-C", str(root / "oracle"), "asan"])
+    env = dict(os.environ, LD_PRELOAD=" ".join(libs), RVA_ORACLE_LIB="liborc_asan.so",
+               ASAN_OPTIONS="detect_leaks=0:halt_on_error=1:abort_on_error=0", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    r = subprocess.run([sys.executable, "-m", "pytest", str(Path(__file__)), "-q", "-x", "-p", "no:cacheprovider",
+                        "-k", "not asan"], cwd=str(root), env=env, capture_output=True, text=True, timeout=900)
+    text = r.stdout + r.stderr
+    assert r.returncode == 0, text[-3000:]
+    assert "AddressSanitizer" not in text and "runtime error" not in text, text[-3000:]
+    assert " passed" in r.stdout
