@@ -210,6 +210,31 @@ def test_pool_upsample_head_primitives():
     assert torch.equal(up, out.repeat_interleave(2, 1).repeat_interleave(2, 2))
 
 
+def _calibrated_error_report(tag, net, x):
+    """The fp16-vs-fp32 numbers north_star speaks in, on weights whose scores MATTER: the seeded network's
+    class biases are shifted (as bench.py does) until ~120 anchors per frame clear conf 0.25 -- an uncalibrated random head
+    scores 1e-5 everywhere and any error looks like zero.  Reported (tests/helpers.py::fp16_error_report -> DESIGN.md section 2):
+    |dscore|, |dbox| in pixels and threshold flips of the plan's fp16 head tensor against the plain fp32 module and against the
+    rounding-matched reference.  Held here: scores within 1e-3 of the rounding-matched reference at p99.9 and within 2e-3 at
+    the maximum (the kernels add nothing beyond fp16 storage); against the fp32 module the MEAN is within 1e-3, the maximum is
+    not -- that part is the fp16 network itself (one rounding per layer), which the reference's `half: true` ORT session shares."""
+    from realtime_video_analytics_32streams_amd.yolov8 import calibrate_detection_density
+    B = x.shape[0]
+    cal = copy.deepcopy(net).fuse().float().cuda()
+    with torch.inference_mode():
+        calibrate_detection_density(cal, x[:min(B, 4)].float(), 0.25, 120)
+        want = torch.cat([cal(x[i:i + 8].float()) for i in range(0, B, 8)])
+        eng = FusedYoloV8(copy.deepcopy(cal), B, autotune=False)
+        got = eng(x)
+        matched = torch.cat([plan_rounded_reference(cal, x[i:i + 8]) for i in range(0, B, 8)])
+    torch.cuda.synchronize()
+    rep = fp16_error_report(tag, got, want, matched)
+    assert rep["vs_fp32_module"]["threshold_flips"]["scores_at_or_above_conf_in_reference"] > 20 * B      # the scores matter
+    assert rep["vs_rounding_matched_reference"]["score"]["p99_9"] < 1e-3 and rep["vs_rounding_matched_reference"]["score"]["max"] < 2e-3
+    assert rep["vs_fp32_module"]["score"]["mean"] < 1e-3 and rep["vs_fp32_module"]["score"]["max"] < 2e-2
+    return rep
+
+
 @pytest.mark.parametrize("scale,batch", [("s", 2), ("n", 2), ("m", 4)])      # m x 4 = one GPU's share of BASELINE configs[3]
 def test_fused_plan_matches_torch_module(scale, batch):
     net = build_detector_net(scale, seed=0)
@@ -229,12 +254,8 @@ def test_fused_plan_matches_torch_module(scale, batch):
     # ... and against the reference that rounds where the plan rounds (fp16 once per layer): a wiring error worth 1e-2 in a
     # score passes the loose bound above, not this one (north_star: coords and scores within 1e-3; the head tensor is fp16,
     # so a coordinate carries half an fp16 ulp of its own on top)
-    matched = plan_rounded_reference(net, x)
-    assert_matches_rounded_reference(eng(x), matched)
-    rep = fp16_error_report(f"{scale}x{batch}", eng(x), want, matched)
-    # north_star's 1e-3 holds against the rounding-matched reference in the mean and at p99.9 of the scores; against the plain
-    # fp32 module it does NOT hold at the maximum (that is the fp16 network itself, not the kernels): stated in DESIGN.md section 2
-    assert rep["vs_rounding_matched_reference"]["score"]["p99_9"] < 1e-3 and rep["vs_fp32_module"]["score"]["mean"] < 1e-3
+    assert_matches_rounded_reference(eng(x), plan_rounded_reference(net, x))
+    _calibrated_error_report(f"{scale}x{batch}", net, x)
 
 
 @pytest.mark.parametrize("shape", [(2, 20, 20, 128, 64, 64), (1, 40, 24, 64, 128, 80), (3, 8, 10, 192, 64, 256)])
@@ -324,8 +345,7 @@ def test_fused_plan_at_bench_size_matches_torch_module():
     assert (got[:, :4] - want[:, :4]).abs().mean() < 0.2
     matched = torch.cat([plan_rounded_reference(net, x[i:i + 8]) for i in range(0, 32, 8)])
     assert_matches_rounded_reference(eng(x), matched)
-    rep = fp16_error_report("sx32", eng(x), want, matched)
-    assert rep["vs_rounding_matched_reference"]["score"]["p99_9"] < 1e-3 and rep["vs_fp32_module"]["score"]["mean"] < 1e-3
+    _calibrated_error_report("sx32", net, x)
     # frames are independent: the plan gives the same answer for a frame wherever it sits in the batch
     y = eng(torch.roll(x, 5, 0)).float()
     assert torch.equal(torch.roll(y, -5, 0), got)
