@@ -400,9 +400,9 @@ def main():
     # HBM traffic of the K1 launch from rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see the file): a
     # committed measurement of exactly this launch shape, not something bench.py can collect while timing
     k1_traffic = None
-    pmc = ROOT / "profiles" / "r03_k1_pmc.json"
+    pmc = ROOT / "profiles" / "r04_k1_pmc.json"
     if pmc.exists() and S == 32 and (args.width, args.height) == (1920, 1080):
-        k1_traffic = json.loads(pmc.read_text())["traffic_bytes_per_launch"]
+        k1_traffic = json.loads(pmc.read_text())["content_1080p"]["traffic_bytes_per_launch"]
     net_tflops = 2 * macs * S / (net_ms * 1e-3) / 1e12
 
     if world > 1:
@@ -441,7 +441,7 @@ def main():
                                "constant letterbox border was written by the first launch into the buffer)", "bound": "hbm",
                      "achieved": round(k1_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(k1_gbs / HBM_PEAK_GBS, 4), "traffic": k1_traffic,
-                     "traffic_source": "profiles/r03_k1_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; not collectable while timing)" if k1_traffic else None,
+                     "traffic_source": "profiles/r04_k1_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; not collectable while timing)" if k1_traffic else None,
                      "algorithmic_bytes_per_launch": k1_frame_bytes * S, "avg_launch_us": round(float(k1_ms) * 1e3, 2),
                      "inputs": f"ring of {ring_frames} surfaces per stream ({ring_frames * S * ((args.width + 255) // 256 * 256) * args.height * 3 // 2 >> 20} MiB "
                                "in all): a surface is read again only after > 2 x 256 MiB of other surfaces, so K1 reads HBM, not the Infinity Cache",
@@ -780,6 +780,10 @@ def extras(args, out, sources, rctx, dev, dcfg, tcfg):
         fn()
         rec = {"kernel": kern, "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "algorithmic_bytes_per_frame": per,
                "algorithmic_bytes_per_launch": per * 8, "traffic": None}
+        pmc = ROOT / "profiles" / "r04_k1_pmc.json"
+        if pmc.exists():                                   # committed PMC passes of exactly this launch shape (tools/r04_n.sh)
+            rec["traffic"] = json.loads(pmc.read_text())["k1_ratio6_4k" if key == "roofline_4k" else "k1_generic_clip_4k"]["traffic_bytes_per_launch"]
+            rec["traffic_source"] = "profiles/r04_k1_pmc.json"
         for state, sweep in (("warm", False), ("cold", True)):
             ms = timed(fn, sweep)
             if ms > 1e-4:

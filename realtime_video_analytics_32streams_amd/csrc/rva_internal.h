@@ -38,6 +38,7 @@ struct rva_ctx {
     // one-shot profiling events for the next K1 (integer-ratio) launch: rva_profile_next_preprocess
     hipEvent_t k1_start = nullptr, k1_stop = nullptr;
     int k1_px = -1;               // RVA_K1_PX tuning switch, read once per context
+    int k1_nt = -1;               // RVA_K1_NT experiment switch (non-temporal loads / stores in the steady-state K1), read once per context
     int num_cus = 0;              // multiProcessorCount of ctx->device (persistent-grid sizing)
 };
 

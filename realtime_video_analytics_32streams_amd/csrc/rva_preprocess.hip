@@ -209,7 +209,10 @@ __global__ void __launch_bounds__(256) k1_ratio(K1Args a)
 // the tensor).  This kernel writes the content region only -- no border branch, so the loads of RPT content rows per
 // thread (half a frame apart) are issued back to back before any arithmetic: twice the bytes in flight per thread and
 // half the workgroups of k1_ratio.  Same taps, same arithmetic, same values as k1_ratio.
-template <int R, typename OutT, int RPT>
+// NT (experiment, RVA_K1_NT=1|2|3 read once per context; profiles/r04_experiments_not_kept.txt #6): non-temporal loads (bit 0) and /
+// or stores (bit 1), so that K1's once-read surfaces and once-written tensor do not evict the convolutions' lines from L2.
+typedef unsigned int k1_u4 __attribute__((ext_vector_type(4)));
+template <int R, typename OutT, int RPT, int NT = 0>
 __global__ void __launch_bounds__(256) k1_ratio_content(K1Args a)
 {
     constexpr int PX = 8;
@@ -236,7 +239,16 @@ __global__ void __launch_bounds__(256) k1_ratio_content(K1Args a)
             const uint2 *ys = reinterpret_cast<const uint2 *>(yp + (size_t)(sy0 + r) * pitch + xoff);
             const uint2 *us = reinterpret_cast<const uint2 *>(uvp + (size_t)((sy0 + r) >> 1) * pitch + xoff);
 #pragma unroll
-            for (int k = 0; k < NW; ++k) { yw[q][r][k] = ys[k]; uw[q][r][k] = us[k]; }
+            for (int k = 0; k < NW; ++k) {
+                if constexpr (NT & 1) {
+                    const unsigned long long ty = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long *>(ys) + k);
+                    const unsigned long long tu = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long *>(us) + k);
+                    yw[q][r][k] = make_uint2((uint32_t)ty, (uint32_t)(ty >> 32));
+                    uw[q][r][k] = make_uint2((uint32_t)tu, (uint32_t)(tu >> 32));
+                } else {
+                    yw[q][r][k] = ys[k]; uw[q][r][k] = us[k];
+                }
+            }
         }
     }
     auto byte_at = [](const uint2 *w, int o) -> int {
@@ -271,9 +283,15 @@ __global__ void __launch_bounds__(256) k1_ratio_content(K1Args a)
             vr[i] = norm_yolo(r, OutT()); vg[i] = norm_yolo(g, OutT()); vb[i] = norm_yolo(b, OutT());
         }
         OutT *out = (OutT *)a.out + (size_t)img * 3 * plane + (size_t)(a.top + r0 + q * rows_per) * a.dst_w + a.left + cx;
-        store8<OutT>(out, vr, true, 8);
-        store8<OutT>(out + plane, vg, true, 8);
-        store8<OutT>(out + 2 * plane, vb, true, 8);
+        if constexpr ((NT & 2) && sizeof(OutT) == 2) {
+            __builtin_nontemporal_store(*reinterpret_cast<const k1_u4 *>(vr), reinterpret_cast<k1_u4 *>(out));
+            __builtin_nontemporal_store(*reinterpret_cast<const k1_u4 *>(vg), reinterpret_cast<k1_u4 *>(out + plane));
+            __builtin_nontemporal_store(*reinterpret_cast<const k1_u4 *>(vb), reinterpret_cast<k1_u4 *>(out + 2 * plane));
+        } else {
+            store8<OutT>(out, vr, true, 8);
+            store8<OutT>(out + plane, vg, true, 8);
+            store8<OutT>(out + 2 * plane, vb, true, 8);
+        }
     }
 }
 
@@ -390,11 +408,21 @@ bool launch_ratio(int R, dim3 grid, hipStream_t s, const K1Args &a, hipEvent_t e
 }
 
 template <int R, typename OutT>
-void launch_content_r(int n, hipStream_t s, const K1Args &a, hipEvent_t e0, hipEvent_t e1)
+void launch_content_r(int n, hipStream_t s, const K1Args &a, hipEvent_t e0, hipEvent_t e1, int nt = 0)
 {
     const int groups = a.new_w / 8;
     if (a.new_h % 2 == 0) {
         dim3 grid(rva_ceil_div(groups * (a.new_h / 2), 256), n);
+        if (nt && R == 3 && sizeof(OutT) == 2) {     // the experiment's forms exist for the headline geometry only (1080p -> 640, fp16)
+            auto go = [&](auto kern) {
+                if (e0 && e1) hipExtLaunchKernelGGL(kern, grid, dim3(256), 0, s, e0, e1, 0, a);
+                else hipLaunchKernelGGL(kern, grid, dim3(256), 0, s, a);
+            };
+            if (nt == 1) go(k1_ratio_content<R, OutT, 2, 1>);
+            else if (nt == 2) go(k1_ratio_content<R, OutT, 2, 2>);
+            else go(k1_ratio_content<R, OutT, 2, 3>);
+            return;
+        }
         if (e0 && e1) hipExtLaunchKernelGGL((k1_ratio_content<R, OutT, 2>), grid, dim3(256), 0, s, e0, e1, 0, a);
         else k1_ratio_content<R, OutT, 2><<<grid, 256, 0, s>>>(a);
     } else {
@@ -405,12 +433,12 @@ void launch_content_r(int n, hipStream_t s, const K1Args &a, hipEvent_t e0, hipE
 }
 
 template <typename OutT>
-bool launch_content(int R, int n, hipStream_t s, const K1Args &a, hipEvent_t e0, hipEvent_t e1)
+bool launch_content(int R, int n, hipStream_t s, const K1Args &a, hipEvent_t e0, hipEvent_t e1, int nt = 0)
 {
     switch (R) {
         case 1: launch_content_r<1, OutT>(n, s, a, e0, e1); return true;
         case 2: launch_content_r<2, OutT>(n, s, a, e0, e1); return true;
-        case 3: launch_content_r<3, OutT>(n, s, a, e0, e1); return true;
+        case 3: launch_content_r<3, OutT>(n, s, a, e0, e1, nt); return true;
         case 4: launch_content_r<4, OutT>(n, s, a, e0, e1); return true;
         case 6: launch_content_r<6, OutT>(n, s, a, e0, e1); return true;
         default: return false;
@@ -485,7 +513,8 @@ int preprocess_common(rva_ctx *ctx, bool nv12, int mode, const void *const *p0, 
         hipEvent_t e0 = ctx->k1_start, e1 = ctx->k1_stop;
         ctx->k1_start = ctx->k1_stop = nullptr;                // one-shot
         if (content_only && !any_mask) {     // the border already holds the pad value: write the content rows only
-            const bool okc = out_dtype == RVA_F16 ? launch_content<__half>(R, n, stream, a, e0, e1) : launch_content<float>(R, n, stream, a, e0, e1);
+            if (ctx->k1_nt < 0) { const char *e = getenv("RVA_K1_NT"); ctx->k1_nt = e ? atoi(e) & 3 : 0; }
+            const bool okc = out_dtype == RVA_F16 ? launch_content<__half>(R, n, stream, a, e0, e1, ctx->k1_nt) : launch_content<float>(R, n, stream, a, e0, e1);
             if (okc) {
                 RVA_HIP(ctx, hipGetLastError());
                 return RVA_OK;

@@ -476,6 +476,9 @@ class PipelinedTicks:
         # K1 of tick k+1 beside the 20x20 phase of tick k's forward pass (most CUs and most of the HBM bandwidth idle there)
         # instead of beside its stem / 80x80 layers: RVA_K1_GATE=1.  Off by default: see DESIGN.md (K1 in the pipeline).
         self.k1_gate = os.environ.get("RVA_K1_GATE", "0") == "1" and self.net_streams >= 2
+        self.k1_prio = os.environ.get("RVA_K1_PRIO", "0") == "1" and self.net_streams >= 2
+        if self.k1_prio:
+            self._k1_stream = torch.cuda.Stream(device=self.det.device, priority=-1)
         # kernel selection objective of plans built from now on: launches timed `net_streams` at a time (see FusedYoloV8.autotune)
         for d in pipe.detectors:
             if is_fused(d) and not getattr(d, "_plans", None):
@@ -609,6 +612,8 @@ class PipelinedTicks:
         sa = self.sAs[par]
         sk = sa                                                    # roi / downsample / K5 / K1 ride on the tick's own stream (a separate,
                                                                    # even high-priority, stream for them cost 20 % of the throughput)
+        if self.k1_prio and self.net_streams >= 2:                 # experiment (RVA_K1_PRIO=1): K1 on ONE high-priority stream of its own
+            sk = self._k1_stream
         self._set_slot(par)
         if self.net_streams >= 2:
             sa.wait_stream(torch.cuda.current_stream())            # whatever the caller queued before this tick (frame sources)
@@ -639,6 +644,8 @@ class PipelinedTicks:
                 if events and gi == 0: events[1].record()
                 if self.two_streams and gi == len(plan.groups) - 1:
                     self._k1_done[par].record(sk)
+                    if sk is not sa:
+                        sa.wait_event(self._k1_done[par])          # the network of this tick follows its K1 on another stream
             with torch.cuda.stream(sa):
                 if self.two_streams and gi == 0 and k >= self.nslots:
                     sa.wait_event(self._done[par])                 # the slot's previous tick has finished reading its head tensors
