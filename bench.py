@@ -78,12 +78,12 @@ def parse():
                          "both are timed during warm-up and the faster one runs the timed region (the graph wins where the host is "
                          "the limit: YOLOv8n x 4 streams)")
     ap.add_argument("--depth", type=int, default=None, choices=[1, 2, 3, 4, 5, 6, 7, 8],
-                    help="ticks in flight, each a chain on its own HIP stream: 3 (default on one GPU) measured +3..7 %% frames/s over 2 at "
-                         "+1.6 ms p99 latency; the runtime has four hardware lanes for streams, so a fourth chain shares one with the "
-                         "default stream and is slower than two; 1 = strictly synchronous ticks (lowest latency).  With sharded streams "
-                         "(--gpus N > 1) the default is 2: a collective on a stream of its own would be a fifth stream (measured with a "
-                         "stand-in: -15 %% with three chains, 0 %% with two, profiles/r03_experiments_not_kept.txt #14) and no 8-GPU record "
-                         "shows yet where RCCL puts it -- pass --depth 3 to compare")
+                    help="ticks in flight, each a chain on its own HIP stream.  Default on one GPU: 4 -- the chains run on streams chosen by "
+                         "a start-up probe so that no two share a hardware lane (ops.chain_streams); measured on one box: 32 x YOLOv8s 21.35 k "
+                         "(3) -> 21.85 k (4) frames/s at p99 4.9 -> 6.5 ms, 4 x YOLOv8m 5 450 -> 6 040, 4 x YOLOv8n 13.6 k -> 15.2 k; five "
+                         "chains are slower than three everywhere.  1 = strictly synchronous ticks (lowest latency).  With sharded streams "
+                         "(--gpus N > 1) the default is 2: no 8-GPU record shows yet which lane RCCL's collective takes "
+                         "(profiles/r03_experiments_not_kept.txt #14) -- pass --depth 3 or 4 to compare")
     return ap.parse_args()
 
 
@@ -169,7 +169,7 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"bench.py: WORLD_SIZE={world} from the launcher but --gpus {args.gpus}; they must agree")
     if args.depth is None:
-        args.depth = 3 if world == 1 else 2        # sharded default: two chains until a SCALE record shows where RCCL puts its collective (--depth 3 to compare)
+        args.depth = 4 if world == 1 else 2        # sharded default: two chains until a SCALE record shows where RCCL puts its collective (--depth 3 / 4 to compare)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP hot path has no CPU fallback")
     if os.environ.get("RVA_SHARE_GPU") != "1" and torch.cuda.device_count() <= local:
@@ -427,6 +427,7 @@ def main():
         "max_latency_ms": round(float(lat.max()) * 1e3, 3), "latency_samples": int(K),
         "host_submit_us_per_tick": {"mean": round(float(t_sub.mean()) * 1e6, 1), "p50": round(float(np.percentile(t_sub, 50)) * 1e6, 1),
                                     "what": "wall time inside PipelinedTicks.submit() on the host thread (every launch of the tick enqueued)"},
+        "chain_stream_probe": ops.chain_stream_report(dev),
         "ticks_in_flight": runner.depth, "network_streams": runner.net_streams, "warmup_ticks_run": warm_ticks, "hip_graph": bool(use_graph), "network_launch": net_launch, "hip_graph_scope": ("network + tail" if runner.replay_net else ("post-process / tracker tail (networks launched eagerly; a tick is one chain on its own stream, consecutive ticks rotate over %d streams)" % runner.net_streams if runner.net_streams >= 2 else "post-process / tracker tail (network launched eagerly: concurrent detect branches)")) if use_graph else None, "realtime_32x30fps": bool(fps / world >= 30.0 * S and np.percentile(lat, 99) < 1 / 30),
         "stages_ms": {"k1_preprocess": round(float(k1_ms), 4), "detector": round(float(net_ms), 4),
                       "k2k3_postprocess": round(float(post_ms), 4), "k4_tracker": round(float(trk_ms), 4)},

@@ -15,17 +15,77 @@ from . import _native as N
 _CHAIN_STREAMS: dict = {}
 
 
+def _probe_lanes(dev_index: int, pool: list, spin_cycles: int = 150_000) -> list:
+    """Which streams of ``pool`` (plus the default stream, index -1) can run kernels side by side?  The HIP runtime multiplexes
+    a process's streams onto a few hardware queues ("lanes": four on this stack, whatever GPU_MAX_HW_QUEUES says), and two streams
+    on one lane serialise.  Measured, not assumed: a spin kernel (~70 us) on stream i and one on stream j, timed from the host --
+    the pair takes one spin when the two have lanes of their own and two when they share one.  Returns the matrix of pair times
+    (ms) as a dict; a few milliseconds at start-up."""
+    import time
+    null = torch.cuda.default_stream(dev_index)
+    streams = {-1: null, **{i: st for i, st in enumerate(pool)}}
+    for st in streams.values():                                   # first use of every stream, in order
+        with torch.cuda.stream(st):
+            torch.cuda._sleep(1000)
+    torch.cuda.synchronize(dev_index)
+
+    def pair(a, b):
+        best = float("inf")
+        for _ in range(2):
+            torch.cuda.synchronize(dev_index)
+            t0 = time.perf_counter()
+            with torch.cuda.stream(streams[a]):
+                torch.cuda._sleep(spin_cycles)
+            if b is not None:
+                with torch.cuda.stream(streams[b]):
+                    torch.cuda._sleep(spin_cycles)
+            torch.cuda.synchronize(dev_index)
+            best = min(best, (time.perf_counter() - t0) * 1e3)
+        return best
+    one = pair(0, None)
+    return {"one": one, "pairs": {(a, b): pair(a, b) for a in streams for b in streams if a < b}}
+
+
 def chain_streams(device, n: int) -> list:
-    """The HIP streams the tick chains of a device run on -- created once per process and shared by everything that runs
-    whole forward passes side by side (``PipelinedTicks``, the kernel selection's in-plan pass).  Which hardware queue a
-    stream gets depends on the streams the process used before it; three chains on streams created AFTER the kernel
-    selection had used three of its own measured 18.0 k frames/s against 21.3 k on the first three streams of the process."""
+    """The HIP streams the tick chains of a device run on -- one set per process, shared by everything that runs whole forward
+    passes side by side (``PipelinedTicks``, the kernel selection).  Which hardware lane a stream gets is the runtime's
+    business and two chains on one lane serialise (three chains measured 18.0 k against 21.3 k frames/s by stream choice alone
+    in round 3; four chains 6 070 against 3 690 frames/s at 4 x YOLOv8m in round 4), so the set is CHOSEN: a pool of eight streams
+    is probed pairwise (``_probe_lanes``) and the chains take streams that share a lane with no other chain -- and, while such
+    streams last, not with the default stream either.  ``RVA_CHAIN_PROBE=0`` takes the first streams created instead."""
+    import os
     dev = torch.device(device) if not isinstance(device, torch.device) else device
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
-    lst = _CHAIN_STREAMS.setdefault(idx, [])
-    while len(lst) < n:
-        lst.append(torch.cuda.Stream(device=idx))
-    return lst[:n]
+    st = _CHAIN_STREAMS.get(idx)
+    if st is None:
+        st = _CHAIN_STREAMS[idx] = {"order": [], "report": None}
+        pool = [torch.cuda.Stream(device=idx) for _ in range(8)]
+        order = list(range(8))
+        if os.environ.get("RVA_CHAIN_PROBE", "1") == "1":
+            rep = _probe_lanes(idx, pool)
+            one = rep["one"]
+            shares = lambda a, b: rep["pairs"][(min(a, b), max(a, b))] > 1.6 * one      # noqa: E731  (two spins back to back: 2 x)
+            chosen: list = []
+            for avoid_null in (True, False):                       # first pass: lanes of their own AND not the default stream's
+                for i in range(8):
+                    if i in chosen or any(shares(i, c) for c in chosen) or (avoid_null and shares(-1, i)):
+                        continue
+                    chosen.append(i)
+            order = chosen + [i for i in range(8) if i not in chosen]
+            st["report"] = {"spin_ms": round(one, 4), "distinct_lanes_found": len(chosen),
+                            "lane_sharing_pairs": sorted([list(k) for k, v in rep["pairs"].items() if v > 1.6 * one]),
+                            "chain_streams": order[:4]}
+        st["pool"], st["order"] = pool, order
+    return [st["pool"][i] for i in st["order"][:n]] if n <= 8 else [st["pool"][i] for i in st["order"]] + \
+        [torch.cuda.Stream(device=idx) for _ in range(n - 8)]
+
+
+def chain_stream_report(device) -> Optional[dict]:
+    """What the lane probe found (None before the first ``chain_streams`` call or with RVA_CHAIN_PROBE=0)."""
+    dev = torch.device(device) if not isinstance(device, torch.device) else device
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    st = _CHAIN_STREAMS.get(idx)
+    return st["report"] if st else None
 
 
 class _Roctx:

@@ -418,11 +418,12 @@ class PipelinedTicks:
                                       "whose clip buffer must only see processed frames (pipeline.py:156-181) -- run them through "
                                       "TickPipeline.tick() (host-decided gates)")
         if depth is None:
-            # Three chains on one GPU.  With sharded streams (pipe.id_sync) two: a collective that lands on a stream of its own
-            # would be a fifth stream on a runtime with four stream lanes -- measured with a stand-in on one GPU: -15 % with
-            # three chains, 0 % with two (profiles/r03_experiments_not_kept.txt #14) -- and no 8-GPU record exists yet that shows
-            # where RCCL puts it; `depth=3` stays available (and is held to the oracle by tests/test_gpu_multirank.py).
-            depth = 3 if pipe.id_sync is None else 2
+            # Four chains on one GPU, on streams probed to have a hardware lane each (ops.chain_streams): +2.3 % frames/s over
+            # three at 32 x YOLOv8s, +11 % at 4 x YOLOv8m (round 4; five are slower than three).  With sharded streams
+            # (pipe.id_sync) two: a collective that lands on a stream of its own takes a lane too -- measured with a stand-in on
+            # one GPU in round 3: -15 % with three chains, 0 % with two (profiles/r03_experiments_not_kept.txt #14) -- and no 8-GPU
+            # record exists yet that shows where RCCL puts it; 3 and 4 stay available (tests/test_gpu_multirank.py holds 3 to the oracle).
+            depth = 4 if pipe.id_sync is None else 2
         if depth not in range(1, 9):
             raise ValueError("depth must be 1 .. 8 (snapshot slots of the tracker, motion-count rows of the gate)")
         self.pipe, self.depth = pipe, depth
