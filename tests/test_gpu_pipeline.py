@@ -48,8 +48,10 @@ def _tab(tracks):
     return [(t.track_id, t.class_id, t.age, t.hits, t.confidence, t.bbox_xyxy) for t in tracks]
 
 
-def test_bench_configuration_end_to_end_against_the_oracle():
-    """BASELINE configs[2] as bench.py runs it (32 x 1080p, YOLOv8s fused plan, depth 2, hipGraphs), 12 ticks."""
+@pytest.mark.parametrize("depth", [2, 4])
+def test_bench_configuration_end_to_end_against_the_oracle(depth):
+    """BASELINE configs[2] as bench.py runs it (32 x 1080p, YOLOv8s fused plan, tick chains on probed streams -- four by default,
+    two as the sharded runs use --, hipGraph tails), 12 ticks."""
     S, T = 32, 12
     streams = [StreamConfig(name=f"cam{i:03d}", url="synthetic://1920x1080", warmup_seconds=0.0) for i in range(S)]
     srcs = [SyntheticNv12Stream(s, index=i, n_unique=3) for i, s in enumerate(streams)]
@@ -58,30 +60,29 @@ def test_bench_configuration_end_to_end_against_the_oracle():
     det = _calibrated("s", streams, srcs, 120)
     tcfg = TrackerConfig(max_age=30, max_iou_distance=0.5, min_hits=1)
     trk = IouTracker(tcfg, max_streams=S, capacity=1024)
-    runner = PipelinedTicks(TickPipeline(streams, det, trk, sources=srcs), depth=2, use_graph=True)
+    runner = PipelinedTicks(TickPipeline(streams, det, trk, sources=srcs), depth=depth, use_graph=True)
+    assert runner.net_streams == depth
     otr = orc.Tracker(S, tcfg.max_age, tcfg.max_iou_distance, tcfg.min_hits)
-    plan = None
     checked = 0
 
     def check(k):
-        nonlocal plan, checked
+        nonlocal checked
         _, tables = runner.collect()
-        if runner.net_streams == 2:      # even / odd ticks run on their own plan (slot 0 / 1), head tensor 0 of that plan
-            head = det._plans[(S, 640, 640) if k % 2 == 0 else (S, 640, 640, 1)]._outs[0].float().cpu().numpy()
-        else:
-            plan = plan or det._plans[(S, 640, 640)]
-            head = plan._outs[k & 1].float().cpu().numpy()        # tick k's head tensor: intact until tick k+2's network
+        par = k % runner.nslots                                    # every slot runs on its own plan, head tensor 0 of that plan:
+        head = det._plans[(S, 640, 640) if par == 0 else (S, 640, 640, par)]._outs[0].float().cpu().numpy()   # intact until tick k + depth's network
         for s in range(S):                                         # canonical order: tick-major, stream-minor
             r = orc.postprocess(head[s], det.config.confidence_threshold, det.config.iou_threshold, None, (1920, 1080))
             m = r["conf"].astype(np.float64) >= det.config.confidence_threshold          # filter_detections
             want = otr.update(s, r["boxes"][m].astype(np.float64), r["conf"][m].astype(np.float64), r["cls"][m].astype(np.int64))
             assert orc.table_of(tables[s]) == orc.table_of(want), (k, s)
             checked += want["n"]
-    runner.submit()
-    for k in range(1, T):
+    done = 0
+    for k in range(T):
+        if k - done == runner.depth:
+            check(done); done += 1
         runner.submit()
-        check(k - 1)
-    check(T - 1)
+    while done < T:
+        check(done); done += 1
     assert runner._captured and checked > 20 * T                  # the graphs were in use and there was something to track
 
 
