@@ -386,3 +386,54 @@ def test_head_fused_conv_is_bit_identical_to_conv_then_head(mode, Cin, Cout):
         untouched = torch.ones_like(got, dtype=torch.bool)
         untouched[:, rows, a0:a0 + H * W] = False
         assert torch.all(got[untouched] == -3.0), variant
+
+
+def test_c_plan_through_the_abi_alone():
+    """rva_yolov8_plan_* driven the way INTEGRATION.md section 2's shim drives it -- ctypes structures built by hand, no engine.py:
+    create from the fused convolutions in module order, one rva_yolov8_plan_run per forward pass -> the head tensor of
+    engine.FusedYoloV8 on the same weights, bit for bit (both detect-branch layouts); a convolution list that does not match the
+    descriptor is refused with a message that names the first misfit; a kernel variant that does not exist is refused."""
+    import numpy as np
+    from realtime_video_analytics_32streams_amd.engine import module_order_convs
+    net = build_detector_net("s", seed=3).fuse()
+    convs = module_order_convs(net)
+    L, ctx = N.lib(), ops.context()
+    keep, arr = [], (N.ConvWeights * len(convs))()
+    for i, c in enumerate(convs):
+        w = np.ascontiguousarray(c.weight.detach().float().numpy()); b = np.ascontiguousarray(c.bias.detach().float().numpy())
+        keep += [w, b]
+        arr[i].weight = w.ctypes.data_as(C.POINTER(C.c_float)); arr[i].bias = b.ctypes.data_as(C.POINTER(C.c_float))
+        arr[i].cout, arr[i].cin, arr[i].k, arr[i].stride = w.shape[0], w.shape[1], w.shape[2], c.stride[0]
+    d = N.YoloV8Desc(batch=2, height=640, width=640, depth_head=1, nc=80, reg_max=16, n_convs=len(convs), flags=0)
+    d.widths[:] = [32, 64, 128, 256, 512]
+    d.depth_backbone[:] = [1, 2, 2, 1]
+    plan = C.c_void_p()
+    ctx.check(L.rva_yolov8_plan_create(ctx.handle, C.byref(d), arr, C.byref(plan)), "rva_yolov8_plan_create")
+    info = [C.c_int32() for _ in range(5)]
+    ctx.check(L.rva_yolov8_plan_info(plan, *[C.byref(v) for v in info]), "info")
+    assert info[0].value == 8400 and info[1].value == 84 and info[2].value == 60 and info[3].value == 58
+    x = torch.rand((2, 3, 640, 640), device="cuda").half()
+    out = torch.zeros((2, 84, 8400), dtype=torch.float16, device="cuda")
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ctx.check(L.rva_yolov8_plan_run(plan, C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()), s), "run")
+    eng = FusedYoloV8(build_detector_net("s", seed=3), 2, autotune=False)
+    want = eng(x).clone()
+    torch.cuda.synchronize()
+    assert torch.equal(out, want) and torch.isfinite(out.float()).all()
+    side = [torch.cuda.Stream(), torch.cuda.Stream()]
+    out2 = torch.zeros_like(out)
+    ctx.check(L.rva_yolov8_plan_run_lanes(plan, C.c_void_p(x.data_ptr()), C.c_void_p(out2.data_ptr()), s, C.c_void_p(side[0].cuda_stream),
+                                          C.c_void_p(side[1].cuda_stream)), "run_lanes")
+    torch.cuda.synchronize()
+    assert torch.equal(out2, want)
+    buf = C.create_string_buffer(96)
+    ctx.check(L.rva_yolov8_plan_tunable_desc(plan, 0, buf, 96), "desc")
+    assert buf.value.decode() == "64->64 k1s1 160x160"
+    assert L.rva_yolov8_plan_set_variant(plan, 0, 10 ** 6) == N.RVA_ERR_ARG and L.rva_yolov8_plan_get_variant(plan, 0) == 0
+    L.rva_yolov8_plan_destroy(plan)
+    # a list that does not fit the descriptor: the error names the first convolution that is off
+    d.widths[2] = 96
+    bad = C.c_void_p()
+    assert L.rva_yolov8_plan_create(ctx.handle, C.byref(d), arr, C.byref(bad)) == N.RVA_ERR_ARG and not bad.value
+    msg = L.rva_last_error(ctx.handle).decode()
+    assert "b3" in msg and "expected 64->96" in msg, msg
