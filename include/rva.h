@@ -370,6 +370,7 @@ int rva_yolo_head3_f16(rva_ctx *ctx, const void *const *box_logits, const int32_
  *   persisted selection).  Results do not depend on the variant beyond fp32 summation order.
  * -------------------------------------------------------------------------------------------- */
 #define RVA_PLAN_NO_STEM2 1   /* rva_yolov8_desc.flags: stem and first downsampling convolution as two launches (A/B switch) */
+#define RVA_PLAN_NO_CIN_PAD 2 /* ... convolutions with Cin % 32 != 0 keep their Cin (default: declared rounded up to 32, zero weights) */
 typedef struct rva_yolov8_plan rva_yolov8_plan;
 typedef struct rva_yolov8_desc {
     int32_t batch, height, width;     /* input tensor; height and width multiples of 32 */

@@ -56,6 +56,7 @@ class ConvWeights(C.Structure):
 
 
 RVA_PLAN_NO_STEM2 = 1
+RVA_PLAN_NO_CIN_PAD = 2
 
 
 def _stale() -> bool:

@@ -85,7 +85,9 @@ struct Builder {
     View buf(long m, int ch)
     {
         View v;
-        v.base = (char *)dev_alloc((size_t)m * ch * 2, true);
+        // + 64 B: a convolution whose Cin is not a multiple of 32 runs with Cin rounded up (zero weights for the extra channels, see
+        // conv()) and reads up to 31 channels past its slice -- the next slice of the row, the next row, or, behind the last row, this slack
+        v.base = (char *)dev_alloc((size_t)m * ch * 2 + 64, true);
         v.ld = ch; v.off = 0; v.ch = ch;
         return v;
     }
@@ -151,7 +153,12 @@ struct Builder {
         if (s.Cin != src.ch || s.Cout != dst.ch) return fail("convolution does not fit its buffers");
         s.in = src.ptr(); s.ldi = src.ld; s.out = dst.ptr(); s.ldo = dst.ld; s.H = h; s.W = w; s.act = act;
         if (res) { s.res = res->ptr(); s.ldr = res->ld; }
-        push(s, "%d->%d k%ds%d %dx%d", s.Cin, s.Cout, s.k, s.stride, h, w);
+        const int cin_real = s.Cin;
+        // Cin 48 / 16 (YOLOv8m / n): the LDS-DMA kernels want whole 32-channel chunks.  The packed weights already carry zero
+        // columns up to the next multiple of 32, so the step simply declares the padded Cin: the extra channels it reads are whatever
+        // follows the slice (finite activations of the neighbouring slice / pixel, or the buffer's zero slack) times zero.
+        if (s.Cin % 32 && !(p->d.flags & RVA_PLAN_NO_CIN_PAD)) s.Cin = (s.Cin + 31) / 32 * 32;
+        push(s, "%d->%d k%ds%d %dx%d", cin_real, s.Cout, s.k, s.stride, h, w);
         return true;
     }
     bool conv1(const rva_conv_weights *c, View src, View dst, int h, int w, int act, const View *res = nullptr)

@@ -109,7 +109,8 @@ class FusedYoloV8:
         d.depth_head = len(net.h12.m)
         assert len(net.h15.m) == len(net.h18.m) == len(net.h21.m) == d.depth_head
         d.nc, d.reg_max, d.n_convs = net.nc, net.detect.reg_max, len(convs)
-        d.flags = N.RVA_PLAN_NO_STEM2 if os.environ.get("RVA_NO_STEM2", "0") == "1" else 0
+        d.flags = (N.RVA_PLAN_NO_STEM2 if os.environ.get("RVA_NO_STEM2", "0") == "1" else 0) | \
+                  (N.RVA_PLAN_NO_CIN_PAD if os.environ.get("RVA_NO_CIN_PAD", "0") == "1" else 0)
         h = C.c_void_p()
         with torch.cuda.device(self.dev):
             self.ctx.check(self.L.rva_yolov8_plan_create(self.ctx.handle, C.byref(d), arr, C.byref(h)), "rva_yolov8_plan_create")
@@ -121,7 +122,7 @@ class FusedYoloV8:
         assert rows == 4 + self.nc
         self.out = torch.empty((batch, rows, self.A), dtype=torch.float16, device=self.dev)
         self._outs = {0: self.out}
-        self.fused_stem = d.flags == 0 and tuple(d.widths[:2]) == (32, 64)
+        self.fused_stem = not (d.flags & N.RVA_PLAN_NO_STEM2) and tuple(d.widths[:2]) == (32, 64)
         # (launch(stream, variant) -> rc, state["variant"], "Cin->Cout kKsS HxW") per convolution step, as the tuner and the tools use them
         self._tunable = []
         buf = C.create_string_buffer(96)
@@ -162,7 +163,7 @@ class FusedYoloV8:
         h.update(repr((self.B, self.H, self.W, [d for _, _, d in self._tunable])).encode())
         h.update(b"per-layer times; in-plan pass opt-in, three overlapping passes")
         h.update(repr([os.environ.get(k, "") for k in ("RVA_SKIP_VARIANTS", "RVA_TUNE_IN_PLAN", "RVA_TUNE_OVERLAP", "RVA_TUNE_TOP",
-                                                       "RVA_TUNE_WITHIN", "RVA_NO_STEM2", "RVA_HEAD_SPLIT")]).encode())
+                                                       "RVA_TUNE_WITHIN", "RVA_NO_STEM2", "RVA_HEAD_SPLIT", "RVA_NO_CIN_PAD")]).encode())
         h.update(repr(int(os.environ.get("RVA_TUNE_LAYER_OVERLAP", getattr(self, "tune_overlap", 1)))).encode())
         return h.hexdigest()[:24]
 
