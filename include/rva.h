@@ -476,6 +476,22 @@ int rva_decoder_next_frame(rva_decoder *dec, void **y, void **uv, int32_t *pitch
                            int64_t *pts, int32_t *pic_index);
 int rva_decoder_release(rva_decoder *dec, int pic_index);
 
+/* ----------------------------------------------------------------------------------------------
+ * K7 device JPEG encoder (round 4) -- replaces cv2.imencode('.jpg', frame, [IMWRITE_JPEG_QUALITY, q, ...]) of
+ * KafkaSink._render_frame (/root/reference/src/realtime_analytics/sinks/kafka_sink.py:260-284) and of
+ * StreamWorker._maybe_save_snapshot (pipeline.py:264-290): a uint8 BGR image in HBM ([height] rows of `pitch` bytes, 3 bytes per
+ * pixel: what rva_preview_nv12 writes) -> a baseline JFIF stream in `out` (device), its length in *out_size (device or mapped
+ * host int32), both written asynchronously on `stream`.  libjpeg's arithmetic step by step (colour conversion, 4:2:0 downsampling,
+ * edge rules, islow DCT, quantisation tables of `quality`), Annex-K Huffman tables, one restart interval per MCU row: a decoder
+ * reconstructs exactly the picture it reconstructs from libjpeg's own file of the same quality (the reference asks for the
+ * progressive, Huffman-optimised form of the same coefficients).  rva_jpeg_max_bytes: a capacity that fits photographic content
+ * (128 B per 8x8 block); rva_jpeg_status (host-synchronous): bit 0 = the stream did not fit since the last call.
+ * -------------------------------------------------------------------------------------------- */
+int rva_jpeg_max_bytes(int width, int height);
+int rva_jpeg_encode_bgr(rva_ctx *ctx, const void *bgr, int pitch, int width, int height, int quality, void *out,
+                        int out_capacity, int32_t *out_size, rva_stream_t stream);
+int rva_jpeg_status(rva_ctx *ctx, rva_stream_t stream, int *flags);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,7 +19,7 @@ ROOT = PKG.parent
 CSRC = PKG / "csrc"
 LIB_PATH = Path(os.environ["RVA_LIB_PATH"]) if os.environ.get("RVA_LIB_PATH") else PKG / "librva.so"   # override: diagnostic builds (tools/)
 SOURCES = ["rva_ctx.hip", "rva_preprocess.hip", "rva_postprocess.hip", "rva_tracker.hip", "rva_conv.hip", "rva_plan.hip", "rva_gates.hip",
-           "rva_decode.hip", "rva_preview.hip"]
+           "rva_decode.hip", "rva_preview.hip", "rva_jpeg.hip"]
 # -ffp-contract=off: parity kernels must not fuse a*b+c (SURVEY.md hard part 4)
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off",
                "-Wall", "-Wno-unused-function"]
@@ -184,6 +184,9 @@ def lib() -> C.CDLL:
         "rva_yolov8_plan_launch_tunable": (C.c_int, [_P, C.c_int, C.c_int, _P, _P]),
         "rva_yolov8_plan_set_variant": (C.c_int, [_P, C.c_int, C.c_int]),
         "rva_yolov8_plan_get_variant": (C.c_int, [_P, C.c_int]),
+        "rva_jpeg_max_bytes": (C.c_int, [C.c_int, C.c_int]),
+        "rva_jpeg_encode_bgr": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P]),
+        "rva_jpeg_status": (C.c_int, [_P, _P, C.POINTER(C.c_int)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError here == header/library mismatch: fail loudly
@@ -209,7 +212,7 @@ EXPORTS = [
     "rva_conv1x1_head_f16", "rva_conv1x1_upcat_f16", "rva_sppf_pool3_nhwc_f16", "rva_maxpool5_nhwc_f16", "rva_upsample2x_nhwc_f16", "rva_yolo_head_f16", "rva_yolo_head3_f16",
     "rva_yolov8_plan_create", "rva_yolov8_plan_destroy", "rva_yolov8_plan_info", "rva_yolov8_plan_run", "rva_yolov8_plan_run_lanes",
     "rva_yolov8_plan_run_range", "rva_yolov8_plan_tunable_desc", "rva_yolov8_plan_launch_tunable", "rva_yolov8_plan_set_variant",
-    "rva_yolov8_plan_get_variant",
+    "rva_yolov8_plan_get_variant", "rva_jpeg_max_bytes", "rva_jpeg_encode_bgr", "rva_jpeg_status",
 ]
 
 

@@ -72,6 +72,7 @@ void rva_destroy(rva_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     free_post(ctx);
+    rva_jpeg_free(ctx);
     free_taps(ctx->taps_x);
     free_taps(ctx->taps_y);
     (void)hipFree(ctx->post_flags);

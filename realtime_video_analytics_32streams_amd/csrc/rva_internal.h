@@ -23,8 +23,11 @@ struct rva_geom_cache {
     rva_resize_table x, y;
 };
 
+struct rva_jpeg_state;           // scratch of the device JPEG encoder (rva_jpeg.hip)
+
 struct rva_ctx {
     int device = 0;
+    rva_jpeg_state *jpeg = nullptr;
     std::string err;
     // post-process scratch, sized by rva_reserve / grown on demand
     int cap_batch = 0, cap_anchors = 0;
@@ -71,3 +74,6 @@ static inline int rva_ceil_div(int a, int b) { return (a + b - 1) / b; }
 // on another device of the same process gets its own call (a process-global `static bool` would skip it).  Must not be
 // reached for the first time inside a stream capture: callers run one eager launch of every kernel before capturing.
 hipError_t rva_func_smem(const void *fn, size_t bytes);
+
+// frees ctx->jpeg (rva_jpeg.hip); called by rva_destroy
+void rva_jpeg_free(rva_ctx *ctx);

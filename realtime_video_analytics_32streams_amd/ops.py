@@ -581,3 +581,29 @@ class DeviceTracker:
 
     def set_next_id(self, v: int):
         self.ctx.check(N.lib().rva_tracker_set_next_id(self.handle, int(v), _stream_ptr()), "rva_tracker_set_next_id")
+
+
+def jpeg_encode_bgr(img: torch.Tensor, quality: int, ctx: Optional[N.Context] = None) -> bytes:
+    """K7: a uint8 BGR image ``[h, w, 3]`` in HBM (what ``preview.render_nv12`` returns) -> baseline JFIF bytes, encoded on the
+    device (``rva_jpeg_encode_bgr``: libjpeg's arithmetic, 4:2:0, Annex-K tables, one restart interval per MCU row).  Only the
+    finished stream crosses PCIe.  Replaces ``cv2.imencode('.jpg', ...)`` of sinks/kafka_sink.py:260-284."""
+    ctx = ctx or context()
+    _require_cuda(img, "image")
+    if img.dtype != torch.uint8 or img.dim() != 3 or img.shape[2] != 3 or img.stride(2) != 1 or img.stride(1) != 3:
+        raise ValueError("jpeg_encode_bgr takes a uint8 [h, w, 3] device tensor with packed pixels")
+    h, w = int(img.shape[0]), int(img.shape[1])
+    L = N.lib()
+    cap = int(L.rva_jpeg_max_bytes(w, h))
+    bufs = ctx.__dict__.setdefault("_jpeg_bufs", {})
+    if cap not in bufs:
+        bufs[cap] = (torch.empty(cap, dtype=torch.uint8, device=img.device), torch.zeros(1, dtype=torch.int32, device=img.device))
+    out, size = bufs[cap]
+    s = _stream_ptr()
+    ctx.check(L.rva_jpeg_encode_bgr(ctx.handle, C.c_void_p(img.data_ptr()), int(img.stride(0)), w, h, int(quality), C.c_void_p(out.data_ptr()),
+                                    cap, C.c_void_p(size.data_ptr()), s), "rva_jpeg_encode_bgr")
+    n = int(size.item())                                            # the one host sync
+    flags = C.c_int(0)
+    ctx.check(L.rva_jpeg_status(ctx.handle, s, C.byref(flags)), "rva_jpeg_status")
+    if flags.value & 1 or not 0 < n <= cap:
+        raise RuntimeError(f"device JPEG encoder: the stream did not fit {cap} bytes ({w}x{h}, quality {quality})")
+    return out[:n].cpu().numpy().tobytes()

@@ -9,7 +9,11 @@ The reference copies every 1080p frame to the host, draws on it with OpenCV and 
     pinned against a call-level recording of its own ``_render_frame`` (tests/golden/preview_plan.json);
   * the PIXELS are produced by one HIP launch on the NV12 surface in HBM (``rva_preview_nv12``: colour conversion, integer
     box downscale, filled rectangles, a built-in 5x7 font), and only the finished preview crosses PCIe;
-  * the ENCODER is Pillow's libjpeg / libwebp on the host (no device encoder exists in the image); the result is a valid
+  * the JPEG ENCODER runs on the device too since round 4 (``ops.jpeg_encode_bgr`` / ``rva_jpeg_encode_bgr``, K7: libjpeg's
+    arithmetic step by step -- a decoder reconstructs exactly the picture it reconstructs from libjpeg's own file of that
+    quality; baseline instead of the reference's progressive + optimised entropy coding of the same coefficients), so only the
+    finished stream (100-300 KB instead of a 6.2 MB image) crosses PCIe; WebP (only when the reference's
+    ``webp_available`` is set and quality >= 80) stays Pillow's libwebp on the host.  The result is a valid
     ``data:image/...;base64,`` URL of the kind the dashboard displays.
 How OpenCV covers pixels for a 2-px outline, its Hershey glyphs, INTER_AREA at non-integer ratios and its encoder's exact
 bits are OpenCV-internal and cannot be pinned here (cv2 is absent): the plan is exact, the raster is this module's own.
@@ -179,9 +183,14 @@ def render_frame(surface, track_list: Sequence[dict], quality: Optional[int] = N
     policy = policy or PreviewPolicy()
     q = policy.base_quality if quality is None else quality
     ops = plan_render((surface.width, surface.height), track_list, q, policy.webp_available)
-    img = render_nv12(surface, ops, ctx=ctx).cpu().numpy()
+    img = render_nv12(surface, ops, ctx=ctx)
     ext, params = next((op[1], op[2]) for op in ops if op[0] == "encode")
-    data, mime = encode_image(img, ext, params)
+    if ext == ".jpg":                                      # encoded where it was rendered: only the stream crosses PCIe
+        from . import ops as O
+        kv = dict(zip(params[0::2], params[1::2]))
+        data, mime = O.jpeg_encode_bgr(img, int(kv.get(IMWRITE_JPEG_QUALITY, 75)), ctx=ctx), "image/jpeg"
+    else:
+        data, mime = encode_image(img.cpu().numpy(), ext, params)
     return f"data:{mime};base64,{base64.b64encode(data).decode('ascii')}"
 
 

@@ -203,3 +203,28 @@ def test_goldens_replay_clean_under_asan_and_ubsan():
     assert r.returncode == 0, text[-3000:]
     assert "AddressSanitizer" not in text and "runtime error" not in text, text[-3000:]
     assert " passed" in r.stdout
+
+
+@pytest.mark.parametrize("w,h,q", [(64, 48, 75), (640, 360, 75), (250, 123, 50), (333, 201, 90), (72, 40, 80), (8, 8, 30), (24, 56, 95),
+                                   (100, 100, 10), (17, 9, 75), (1, 1, 75), (33, 47, 100), (640, 362, 1), (1288, 728, 55)])
+def test_jpeg_oracle_is_pinned_by_pillows_libjpeg(w, h, q):
+    """oracle/jpeg_oracle.py (the CPU restatement the device JPEG encoder K7 is held to) against libjpeg itself: Pillow's
+    libjpeg-turbo decodes this encoder's stream to EXACTLY the pixels it decodes from its own encoding of the same BGR image at the
+    same quality and 4:2:0 sampling, and reports the same quantisation tables -- i.e. colour conversion, edge rules (last column
+    before / last downsampled row after the 2x2 chroma downsampling, dummy luma blocks), islow DCT and quantisation are libjpeg's;
+    only the entropy coding differs (baseline + restart markers here, which the decoder checks by decoding).  Geometries: whole
+    MCUs, 8- and odd-pixel remainders on both axes, a single pixel, quality 1 .. 100."""
+    import io
+    from PIL import Image
+    from oracle import jpeg_oracle as J
+    from realtime_video_analytics_32streams_amd import synth
+    bgr = synth.make_bgr(7 + w, w, h)
+    data = J.encode(bgr, q)
+    mine = Image.open(io.BytesIO(data)); mine.load()
+    buf = io.BytesIO()
+    Image.fromarray(np.ascontiguousarray(bgr[..., ::-1])).save(buf, format="JPEG", quality=q, subsampling="4:2:0")
+    ref = Image.open(io.BytesIO(buf.getvalue())); ref.load()
+    assert mine.size == ref.size == (w, h)
+    assert {k: list(v) for k, v in mine.quantization.items()} == {k: list(v) for k, v in ref.quantization.items()}
+    assert np.array_equal(np.asarray(mine.convert("RGB")), np.asarray(ref.convert("RGB")))
+    assert len(data) < len(buf.getvalue()) * 1.05 + 64            # the restart markers cost a few bytes per MCU row, no more
