@@ -228,3 +228,46 @@ def test_jpeg_oracle_is_pinned_by_pillows_libjpeg(w, h, q):
     assert {k: list(v) for k, v in mine.quantization.items()} == {k: list(v) for k, v in ref.quantization.items()}
     assert np.array_equal(np.asarray(mine.convert("RGB")), np.asarray(ref.convert("RGB")))
     assert len(data) < len(buf.getvalue()) * 1.05 + 64            # the restart markers cost a few bytes per MCU row, no more
+
+
+@pytest.mark.parametrize("w,h", [(1280, 720), (1000, 562), (853, 480), (1920, 1080), (719, 1281), (640, 360)])
+def test_preprocess_oracle_agrees_with_an_independent_float_bilinear(w, h):
+    """P1 is PARITY-UNPINNED against OpenCV itself (cv2 absent, no fixture in the reference).  What CAN be checked without it: the
+    oracle's restatement of cv2.resize(INTER_LINEAR) -- tap positions from fx = (dx + 0.5) scale - 0.5, 11-bit weights, the
+    fixed-point vertical pass -- against an independent implementation of the same sampling rule in floating point
+    (torch.nn.functional.interpolate, bilinear, align_corners=False: half-pixel centres, no antialiasing), plus the letterbox
+    geometry and the 114 border.  Agreement within ONE grey level everywhere (the integer output's own rounding + the 11-bit
+    weights) says the taps and weights are right; it cannot say the last bit is OpenCV's -- that stays unpinned."""
+    import torch
+    import torch.nn.functional as F
+    from realtime_video_analytics_32streams_amd import synth
+    bgr = synth.make_bgr(3 + w, w, h)
+    out, meta = orc.preprocess_bgr(bgr, 640, 640, False)              # float32 [3, 640, 640], RGB / 255, letterboxed
+    scale = min(640 / w, 640 / h)
+    nw, nh = int(w * scale), int(h * scale)
+    assert meta["scale"] == scale
+    x = torch.from_numpy(bgr[..., ::-1].copy()).permute(2, 0, 1)[None].float()
+    ref = F.interpolate(x, size=(nh, nw), mode="bilinear", align_corners=False, antialias=False)[0].numpy()
+    left, top = meta["pad"]
+    got = out[:, top:top + nh, left:left + nw] * 255.0
+    assert np.abs(got - ref).max() < 1.0, float(np.abs(got - ref).max())
+    assert np.abs(got - ref).mean() < 0.3
+    border = np.ones_like(out, dtype=bool)
+    border[:, top:top + nh, left:left + nw] = False
+    assert np.allclose(out[border], np.float32(114.0) / np.float32(255.0))
+
+
+def test_nv12_colour_matrix_agrees_with_the_bt601_definition():
+    """The NV12 -> BGR step in front of P1 stands in for what FFmpeg's swscale hands cv2.VideoCapture (unpinned: neither is
+    present).  Independent check of the integer matrix the oracle and K1 use (298 / 409 / 208 / 100 / 516, >> 8) against the
+    BT.601 limited-range DEFINITION in floating point (R = 1.164 (Y - 16) + 1.596 (Cr - 128), ...), nearest chroma: within one
+    grey level for every (Y, Cb, Cr) of a synthetic frame, exact clipping at both ends."""
+    from realtime_video_analytics_32streams_amd import synth
+    y, uv = synth.make_nv12(11, 640, 360, 768)
+    bgr = orc.nv12_to_bgr(y, uv, 640, 360).astype(np.float64)
+    Y = y[:360, :640].astype(np.float64) - 16.0
+    cb = np.repeat(np.repeat(uv[:180, 0:640:2].astype(np.float64), 2, 0), 2, 1) - 128.0
+    cr = np.repeat(np.repeat(uv[:180, 1:640:2].astype(np.float64), 2, 0), 2, 1) - 128.0
+    ref = np.stack([1.164383 * Y + 2.017232 * cb, 1.164383 * Y - 0.391762 * cb - 0.812968 * cr, 1.164383 * Y + 1.596027 * cr], -1)
+    ref = np.clip(ref, 0.0, 255.0)
+    assert np.abs(bgr - ref).max() <= 1.0 and np.abs(bgr - ref).mean() < 0.4
