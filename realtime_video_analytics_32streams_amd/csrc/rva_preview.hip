@@ -25,14 +25,20 @@ struct K6Args {
 
 __device__ __forceinline__ int clip8(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
 
-// 5x7 font: digits, 'I', 'D', space; row-major, bit 4 = leftmost column
-__constant__ uint8_t kFont[13][7] = {
+// 5x7 font: digits, 'I', 'D', space, then 'c', 'l', 's' (the snapshot label "ID<id> cls<class>", pipeline.py:279); row-major,
+// bit 4 = leftmost column
+__constant__ uint8_t kFont[16][7] = {
     {0x0E, 0x11, 0x13, 0x15, 0x19, 0x11, 0x0E}, {0x04, 0x0C, 0x04, 0x04, 0x04, 0x04, 0x0E}, {0x0E, 0x11, 0x01, 0x02, 0x04, 0x08, 0x1F},
     {0x1F, 0x02, 0x04, 0x02, 0x01, 0x11, 0x0E}, {0x02, 0x06, 0x0A, 0x12, 0x1F, 0x02, 0x02}, {0x1F, 0x10, 0x1E, 0x01, 0x01, 0x11, 0x0E},
     {0x06, 0x08, 0x10, 0x1E, 0x11, 0x11, 0x0E}, {0x1F, 0x01, 0x02, 0x04, 0x08, 0x08, 0x08}, {0x0E, 0x11, 0x11, 0x0E, 0x11, 0x11, 0x0E},
     {0x0E, 0x11, 0x11, 0x0F, 0x01, 0x02, 0x0C}, {0x0E, 0x04, 0x04, 0x04, 0x04, 0x04, 0x0E}, {0x1E, 0x11, 0x11, 0x11, 0x11, 0x11, 0x1E},
-    {0, 0, 0, 0, 0, 0, 0}};
-__device__ __forceinline__ int font_row(int ch) { return ch >= '0' && ch <= '9' ? ch - '0' : (ch == 'I' ? 10 : (ch == 'D' ? 11 : 12)); }
+    {0, 0, 0, 0, 0, 0, 0},
+    {0x00, 0x00, 0x0E, 0x10, 0x10, 0x11, 0x0E}, {0x0C, 0x04, 0x04, 0x04, 0x04, 0x04, 0x0E}, {0x00, 0x00, 0x0F, 0x10, 0x0E, 0x01, 0x1E}};
+__device__ __forceinline__ int font_row(int ch)
+{
+    if (ch >= '0' && ch <= '9') return ch - '0';
+    switch (ch) { case 'I': return 10; case 'D': return 11; case 'c': return 13; case 'l': return 14; case 's': return 15; default: return 12; }
+}
 
 __global__ void __launch_bounds__(256) k6_preview(K6Args a)
 {

@@ -119,6 +119,7 @@ class TickPipeline:
             self.global_index[sl] = first_global_index + i
         self.n_global = n_global_streams or len(self.streams)
         self._tick = 0
+        self.snapshots = None          # a preview.SnapshotWriter: StreamWorker._maybe_save_snapshot (pipeline.py:196, 264-290)
         # pre-detector gates, configured by the reference's StreamConfig keys
         self.adaptive = [AdaptiveFps(s) for s in self.streams]
         self._motion: Optional[MotionGate] = None
@@ -348,6 +349,10 @@ class TickPipeline:
             tracks[n] = self.tracker._materialise(n, t, host_dets.get(i, ()))
         host_dets.clear()
         emitted = {self.names[i]: int(emitted_all[self.slots[i]]) for i in live if processed_all[self.slots[i]] == 1}
+        if self.snapshots is not None:                                # processed frames only, once per stream per five minutes; the
+            for i, n in zip(live, names):                             # frame's surface must still be alive when its tick is collected
+                if n in emitted:
+                    self.snapshots.maybe_save(packets[i], tracks[n])
         for n in names:
             self.counters.update(n, 1, emitted.get(n, 0), len(tracks[n]))
         self._tick += 1

@@ -126,6 +126,32 @@ def raster_primitives(ops: Sequence[list], size_wh: Tuple[int, int], glyph_scale
             np.asarray(glyphs, np.int32).reshape(-1, 3))
 
 
+def render_bgr(frame, ops: Sequence[list], glyph_scale: int = 2, ctx=None):
+    """A plan without a resize drawn over a COPY of a BGR frame -- ``[h, w, 3]`` uint8, a host ndarray as cv2.VideoCapture
+    delivers it (uploaded once) or a device tensor: K6 with ratio 0 draws in place on the copy."""
+    import torch
+    from . import _native as N
+    from . import ops as O
+    ctx = ctx or O.context()
+    if any(op[0] == "resize" for op in ops):
+        raise ValueError("render_bgr draws at the frame's own size; a resizing plan needs the NV12 surface (render_nv12)")
+    src = torch.from_numpy(np.ascontiguousarray(frame)) if isinstance(frame, np.ndarray) else frame
+    if src.dtype != torch.uint8 or src.dim() != 3 or src.shape[2] != 3:
+        raise ValueError("render_bgr expects a [h, w, 3] uint8 BGR image")
+    out = src.cuda().contiguous().clone() if src.is_cuda else src.cuda().contiguous()
+    th, tw = int(out.shape[0]), int(out.shape[1])
+    rects, colors, glyphs = raster_primitives(ops, (tw, th), glyph_scale)
+    dev = out.device
+    d_r = torch.from_numpy(rects).to(dev) if len(rects) else None
+    d_c = torch.from_numpy(colors).to(dev) if len(rects) else None
+    d_g = torch.from_numpy(glyphs).to(dev) if len(glyphs) else None
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None      # noqa: E731
+    rc = N.lib().rva_preview_nv12(ctx.handle, None, None, 0, tw, th, 0, p(out), tw, th, p(d_r), p(d_c), len(rects), p(d_g), len(glyphs),
+                                  glyph_scale, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    ctx.check(rc, "rva_preview_nv12")
+    return out
+
+
 def render_nv12(surface, ops: Sequence[list], glyph_scale: int = 2, ctx=None):
     """The preview image of a plan for an NV12 surface in HBM: uint8 BGR ``[h, w, 3]`` device tensor (one K6 launch; a
     non-integer downscale goes through the INTER_LINEAR resize stage first, a documented deviation from INTER_AREA)."""
@@ -199,3 +225,81 @@ def attach_preview(payload: dict, surface, policy: PreviewPolicy, ctx=None) -> d
     if surface is not None and policy.should_send_frame(payload["stream"]):
         payload["frame_jpeg"] = render_frame(surface, payload["tracks"], policy.adaptive_quality(len(payload["tracks"])), policy, ctx)
     return payload
+
+
+# ---------------------------------------------------------------------------------------------- five-minute snapshots
+SNAPSHOT_INTERVAL = 300.0                     # pipeline.py:269
+SNAPSHOT_ROOT = "/data/outputs"               # pipeline.py:282
+SNAPSHOT_COLOR = (0, 204, 255)                # pipeline.py:278, BGR
+SNAPSHOT_JPEG_QUALITY = 95                    # cv2.imwrite's default for ".jpg" (no parameters are passed, pipeline.py:287)
+
+
+def _field(track, name, default=None):
+    return track.get(name, default) if isinstance(track, dict) else getattr(track, name, default)
+
+
+def plan_snapshot(stream_name: str, frame_id: int, now: float, frame_wh: Tuple[int, int], track_list: Sequence,
+                  root: str = SNAPSHOT_ROOT) -> List[list]:
+    """What ``StreamWorker._maybe_save_snapshot`` does once a snapshot is due (pipeline.py:275-288), in the form of the golden
+    recording (tests/golden/snapshot_plan.json): the frame is copied, every track gets a 2-px outline in one fixed colour
+    and the label ``ID<track_id> cls<class_id>`` (``ID cls<class_id>`` for an object without a track id) 6 px above its top-left
+    corner, the stream's directory is made and the image is written as ``<int(now)>_frame<frame_id>.jpg``.  Tracks are Track /
+    Detection objects or wire dicts."""
+    w, h = frame_wh
+    ops: List[list] = [["copy", [h, w]]]
+    for t in track_list:
+        x1, y1, x2, y2 = [int(v) for v in _field(t, "bbox_xyxy")]
+        ops.append(["rectangle", [x1, y1], [x2, y2], list(SNAPSHOT_COLOR), 2])
+        tid = _field(t, "track_id")
+        ops.append(["text", f"ID{'' if tid is None else tid} cls{_field(t, 'class_id')}", [x1, max(0, y1 - 6)], 0.5, [255, 255, 255], 1])
+    out_dir = f"{root.rstrip('/')}/{stream_name}"
+    ops.append(["mkdir", out_dir, True, True])
+    ops.append(["imwrite", f"{out_dir}/{int(now)}_frame{frame_id}.jpg", [h, w]])
+    return ops
+
+
+class SnapshotWriter:
+    """``StreamWorker._maybe_save_snapshot`` for every stream of a pipeline (the reference keeps ``_last_snapshot_ts`` per
+    worker, one worker per stream; pipeline.py:93, 264-290): at most one annotated frame per stream per 300 s, drawn (K6) and
+    JPEG-encoded (K7) on the device -- the finished file is the only thing that crosses PCIe.  Like the reference, a failure to
+    write is logged, not raised."""
+
+    def __init__(self, root: str = SNAPSHOT_ROOT, clock: Callable[[], float] = time.time, interval: float = SNAPSHOT_INTERVAL, ctx=None):
+        self.root, self._clock, self.interval, self.ctx = root, clock, interval, ctx
+        self._last: dict = {}
+        self.written: List[str] = []
+
+    def due(self, stream_name: str) -> Optional[float]:
+        """The timestamp to file the snapshot under if one is due now (and note it as taken), else None."""
+        now = self._clock()
+        if now - self._last.get(stream_name, 0.0) < self.interval:
+            return None
+        self._last[stream_name] = now
+        return now
+
+    def maybe_save(self, packet, track_list: Sequence) -> Optional[str]:
+        """``packet``: a FramePacket whose frame is an Nv12Surface in HBM or a host BGR ndarray.  Returns the path written."""
+        import logging
+        name = packet.stream.name
+        now = self.due(name)
+        if now is None:
+            return None
+        frame = packet.frame
+        is_bgr = isinstance(frame, np.ndarray) or hasattr(frame, "dim")
+        wh = (int(frame.shape[1]), int(frame.shape[0])) if is_bgr else (frame.width, frame.height)
+        ops = plan_snapshot(name, packet.frame_id, now, wh, track_list, self.root)
+        from . import ops as O
+        img = render_bgr(frame, ops, ctx=self.ctx) if is_bgr else render_nv12(frame, ops, ctx=self.ctx)
+        data = O.jpeg_encode_bgr(img, SNAPSHOT_JPEG_QUALITY, ctx=self.ctx)
+        path = next(op[1] for op in ops if op[0] == "imwrite")
+        try:
+            import os
+            os.makedirs(next(op[1] for op in ops if op[0] == "mkdir"), exist_ok=True)
+            with open(path, "wb") as f:
+                f.write(data)
+        except Exception as exc:  # noqa: BLE001  pipeline.py:289-290
+            logging.getLogger(__name__).error("Failed to save snapshot for '%s': %s", name, exc)
+            return None
+        logging.getLogger(__name__).info("Saved snapshot for '%s' to %s", name, path)
+        self.written.append(path)
+        return path

@@ -126,16 +126,24 @@ def test_tick_pipeline_equals_per_stream_reference_order():
     assert total > 0
 
 
-def test_tick_pipeline_skipped_and_missing_frames():
+def test_tick_pipeline_skipped_and_missing_frames(tmp_path):
+    from realtime_video_analytics_32streams_amd.preview import SnapshotWriter
     streams, det, trk, srcs = _make_pipe(3)
     srcs[2].n_frames = 2                                  # stream 2 runs dry after two frames
     pipe = TickPipeline(streams, det, trk, sources=srcs)
+    now = [5000.0]
+    pipe.snapshots = SnapshotWriter(root=str(tmp_path), clock=lambda: now[0])
+    r0 = pipe.tick(process=[True, False, True])           # stream 1's frame is gated out: no snapshot of an unprocessed frame
+    assert sorted(pipe.snapshots.written) == [f"{tmp_path}/cam0/5000_frame0.jpg", f"{tmp_path}/cam2/5000_frame0.jpg"]
     r0 = pipe.tick()
+    assert pipe.snapshots.written[2:] == [f"{tmp_path}/cam1/5000_frame1.jpg"]          # pipeline.py:196: the first processed frame
     n0 = {k: len(v) for k, v in r0.tracks.items()}
     r1 = pipe.tick(process=[True, False, True])           # stream 1's frame is gated out: update(name, [])
     assert all(t.age == 1 for t in r1.tracks["cam1"]) and len(r1.tracks["cam1"]) == n0["cam1"]
+    now[0] += 300.0
     r2 = pipe.tick()
     assert "cam2" not in r2.tracks and set(r2.tracks) == {"cam0", "cam1"}   # dry stream masked, others unaffected
+    assert len(pipe.snapshots.written) == 5               # five minutes later: the two live streams again
 
 
 def test_detector_self_parity_fp16_gpu_vs_fp32_cpu():
@@ -472,3 +480,43 @@ def test_preview_frame_jpeg_is_encoded_on_the_device():
     url = P.render_frame(surf, tracks, 75)
     assert url.startswith("data:image/jpeg;base64,")
     assert base64.b64decode(url.split(",", 1)[1]) == J.encode(img, 75)
+
+
+def test_five_minute_snapshot_is_drawn_and_encoded_on_the_device(tmp_path):
+    """``preview.SnapshotWriter`` (StreamWorker._maybe_save_snapshot, pipeline.py:264-290) on an NV12 surface in HBM and on a
+    host BGR frame: the file lands under ``<root>/<stream>/<int(now)>_frame<id>.jpg``, holds exactly the oracle's JPEG bytes
+    (quality 95, cv2.imwrite's default) of the image K6 drew for the recorded plan, a second frame inside the interval writes
+    nothing, and every label character of "ID<id> cls<class>" has a glyph (white pixels where the plan puts the label)."""
+    from oracle import jpeg_oracle as J
+    from realtime_video_analytics_32streams_amd import preview as P
+    from realtime_video_analytics_32streams_amd.video_stream import FramePacket
+    from realtime_video_analytics_32streams_amd.config import StreamConfig
+    from realtime_video_analytics_32streams_amd.tracker import Track
+    w, h = 1920, 1080
+    y, uv = synth.make_nv12(21, w, h, 2048)
+    surf = ops.Nv12Surface.from_numpy(y, uv, w, h)
+    bgr = synth.make_bgr(22, 640, 360)
+    tracks = [Track(track_id=42, class_id=7, confidence=0.9, bbox_xyxy=(200.5, 150.2, 500.9, 300.1)),
+              Track(track_id=1305, class_id=0, confidence=0.8, bbox_xyxy=(20.0, 3.0, 120.0, 90.0))]
+    now = [1000.7]
+    wr = P.SnapshotWriter(root=str(tmp_path), clock=lambda: now[0])
+    for name, frame, wh in (("cam-a", surf, (w, h)), ("cam-b", bgr, (640, 360))):
+        st = StreamConfig(name=name, url="x")
+        path = wr.maybe_save(FramePacket(stream=st, frame=frame, frame_id=17, timestamp=0.0), tracks)
+        assert path == f"{tmp_path}/{name}/1000_frame17.jpg"
+        plan = P.plan_snapshot(name, 17, now[0], wh, tracks, str(tmp_path))
+        img = (P.render_nv12(surf, plan) if name == "cam-a" else P.render_bgr(bgr, plan)).cpu().numpy()
+        base = orc.nv12_to_bgr(y, uv, w, h) if name == "cam-a" else bgr
+        assert open(path, "rb").read() == J.encode(img, 95)
+        changed = (img != base).any(-1)
+        assert (img[149:151, 199:501] == (0, 204, 255)).all()                           # the 2-px outline of the first box
+        for k, ch in enumerate("ID42 cls7"):                                            # every character but the blank draws
+            cell = (slice(150 - 6 - 14, 150 - 6), slice(200 + 12 * k, 200 + 12 * k + 10))
+            assert bool(changed[cell].any()) == (ch != " "), ch
+            assert (img[cell][changed[cell]] == 255).all()
+        assert wr.maybe_save(FramePacket(stream=st, frame=frame, frame_id=18, timestamp=0.0), tracks) is None
+    assert bgr is not None and (bgr == synth.make_bgr(22, 640, 360)).all()             # the host frame itself is untouched
+    now[0] += 300.0
+    st = StreamConfig(name="cam-a", url="x")
+    assert wr.maybe_save(FramePacket(stream=st, frame=surf, frame_id=99, timestamp=0.0), []) == f"{tmp_path}/cam-a/1300_frame99.jpg"
+    assert len(wr.written) == 3

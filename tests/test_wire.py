@@ -71,6 +71,29 @@ def test_preview_plan_and_policy_match_reference_recording():
     assert got == g["rate"]
 
 
+def test_snapshot_plan_and_interval_match_reference_recording():
+    """8f-3, the five-minute snapshot: tests/golden/snapshot_plan.json is StreamWorker._maybe_save_snapshot (pipeline.py:264-290)
+    recorded at the cv2 / Path call level under a scripted clock -- when a snapshot is taken (300 s per stream, first frame
+    always), the copy, every outline and label with integer coordinates, colour and thickness, the directory and the file name."""
+    from types import SimpleNamespace
+    from realtime_video_analytics_32streams_amd import preview as P
+    from tests.conftest import load_golden
+    g = load_golden("snapshot_plan.json")
+    assert sum(1 for c in g if c["calls"]) >= 3 and sum(1 for c in g if not c["calls"]) >= 3
+    now = [0.0]
+    wr = P.SnapshotWriter(clock=lambda: now[0])
+    for c in g:
+        now[0] = c["now"]
+        at = wr.due(c["stream"])
+        assert (at is not None) == bool(c["calls"]), c["now"]
+        if at is None:
+            continue
+        as_objects = [SimpleNamespace(**{k: v for k, v in t.items() if not (k == "track_id" and v is None)}) for t in c["tracks"]]
+        for tracks in (c["tracks"], as_objects):                   # wire dicts and Track / Detection objects alike
+            assert P.plan_snapshot(c["stream"], c["frame_id"], at, tuple(c["wh"]), tracks) == c["calls"], c["now"]
+    assert wr.due("another-stream") is not None                    # the interval is per stream
+
+
 def test_preview_encoder_roundtrip_on_host():
     """The host encoder (Pillow standing in for cv2.imencode): a data URL whose payload decodes back to the image."""
     import base64, io
