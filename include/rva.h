@@ -159,6 +159,11 @@ int rva_postprocess_batch(rva_ctx *ctx, const void *raw, int raw_dtype, int batc
 /* Host-synchronous: bit 0 = max_det overflow, bit 1 = candidate capacity overflow since the last call. */
 int rva_post_status(rva_ctx *ctx, rva_stream_t stream, int *flags);
 
+/* Host-synchronous diagnostic: the number of images since the last call whose NMS scanned the kept list through the centre-bin
+ * filter (K3: proper boxes -- x1 <= x2, y1 <= y2 for every candidate of the image -- and 0.15 <= iou_thr <= 0.999; other images
+ * take the unfiltered scan, same result).  Nothing in the reference corresponds to it; the tests use it to know which path ran. */
+int rva_post_filter_stats(rva_ctx *ctx, rva_stream_t stream, int *binned_images);
+
 /* ----------------------------------------------------------------------------------------------
  * K4 tracker -- replaces IouTracker (tracker.py:45-147) for all streams of this process.
  *

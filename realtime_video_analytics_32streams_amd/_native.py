@@ -128,6 +128,7 @@ def lib() -> C.CDLL:
                                             C.c_int, C.POINTER(Letterbox), C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P,
                                             _P]),
         "rva_post_status": (C.c_int, [_P, _P, C.POINTER(C.c_int)]),
+        "rva_post_filter_stats": (C.c_int, [_P, _P, C.POINTER(C.c_int)]),
         "rva_tracker_create": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.POINTER(_P)]),
         "rva_tracker_destroy": (None, [_P]),
         "rva_tracker_update_f32": (C.c_int, [_P, i32p, _P, _P, _P, _P, C.c_int, C.c_double, _P]),
@@ -201,7 +202,7 @@ def lib() -> C.CDLL:
 EXPORTS = [
     "rva_abi_version", "rva_create", "rva_destroy", "rva_last_error", "rva_reserve", "rva_letterbox_meta",
     "rva_preprocess_nv12_batch", "rva_preprocess_nv12_content_batch", "rva_preprocess_bgr_batch", "rva_preprocess_clip_nv12_batch",
-    "rva_preprocess_clip_bgr_batch", "rva_profile_next_preprocess", "rva_preprocess_frames_nv12_batch", "rva_preprocess_frames_bgr_batch", "rva_postprocess_batch", "rva_post_status", "rva_tracker_create",
+    "rva_preprocess_clip_bgr_batch", "rva_profile_next_preprocess", "rva_preprocess_frames_nv12_batch", "rva_preprocess_frames_bgr_batch", "rva_postprocess_batch", "rva_post_status", "rva_post_filter_stats", "rva_tracker_create",
     "rva_tracker_destroy", "rva_tracker_update_f32", "rva_tracker_update_f64", "rva_tracker_update_gated_f32",
     "rva_tracker_set_gates", "rva_tracker_snapshot_status", "rva_tracker_new_counts",
     "rva_tracker_assign_ids", "rva_tracker_read", "rva_tracker_read_all", "rva_tracker_snapshot_async",

@@ -36,8 +36,8 @@ int rva_create(int device, rva_ctx **out)
     if (hipSetDevice(device) != hipSuccess) return RVA_ERR_HIP;
     rva_ctx *ctx = new rva_ctx();
     ctx->device = device;
-    if (hipMalloc(&ctx->post_flags, sizeof(int32_t)) != hipSuccess ||
-        hipMemset(ctx->post_flags, 0, sizeof(int32_t)) != hipSuccess) {
+    if (hipMalloc(&ctx->post_flags, sizeof(int32_t) * (2 + RVA_MAX_BATCH)) != hipSuccess ||
+        hipMemset(ctx->post_flags, 0, sizeof(int32_t) * (2 + RVA_MAX_BATCH)) != hipSuccess) {
         delete ctx;
         return RVA_ERR_HIP;
     }

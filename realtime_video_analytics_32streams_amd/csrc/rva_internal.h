@@ -35,7 +35,7 @@ struct rva_ctx {
     float *sp_score = nullptr;    // [B][A]
     int32_t *sp_cls = nullptr;    // [B][A]
     uint32_t *cand_bits = nullptr;// [B][ceil(A/32)] pass bitmap in anchor order
-    int32_t *post_flags = nullptr;// [1]
+    int32_t *post_flags = nullptr;// [2 + RVA_MAX_BATCH]: overflow flags, K2's improper-box flag per image of the launch, images NMS'd with the centre-bin filter
     // resize tap tables keyed by (src, dst) per axis
     std::map<uint64_t, rva_resize_table> taps_x, taps_y;
     // one-shot profiling events for the next K1 (integer-ratio) launch: rva_profile_next_preprocess

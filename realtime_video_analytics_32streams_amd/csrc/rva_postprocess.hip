@@ -27,6 +27,7 @@
 #include <hip/hip_fp16.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "rva_internal.h"
@@ -50,6 +51,8 @@ struct K2Args {
     int32_t *sp_cls;
     uint32_t *bits;
     int nwords;
+    int32_t *irr;     // [batch] set when a candidate box of the image has x1 > x2 or y1 > y2 (negative raw width / height): K3's
+                      // centre-bin filter assumes proper boxes and steps aside for such an image
 };
 
 __device__ __forceinline__ float ldf(const float *p) { return *p; }
@@ -61,7 +64,7 @@ __global__ void __launch_bounds__(256) k2_decode(K2Args a)
     const int b = blockIdx.y;
     const int anchor = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    bool pass = false;
+    bool pass = false, odd = false;
     if (anchor < a.A) {
         const T *p = (const T *)a.raw + (long)b * a.sb + (long)anchor * a.sa;
         float best;
@@ -92,8 +95,10 @@ __global__ void __launch_bounds__(256) k2_decode(K2Args a)
             a.sp_box[o] = make_float4(x1, y1, x2, y2);
             a.sp_score[o] = best;
             a.sp_cls[o] = bi;
+            odd = !(x1 <= x2) || !(y1 <= y2);
         }
     }
+    if (__any(odd) && lane == 0) atomicOr(a.irr + b, 1);          // practically never: real heads have w, h >= 0
     const unsigned long long mask = __ballot(pass);
     // pass bitmap: this wave owns anchors [a0, a0+64) = words a0/32 and a0/32+1 (written whole)
     const int a0 = blockIdx.x * 256 + (threadIdx.x & ~63);
@@ -182,8 +187,6 @@ struct K3Args {
     const int32_t *sp_cls;
     const uint32_t *bits;
     int nwords, A, kcap;  // kcap: power of two, LDS key capacity
-    int kbl;              // kept boxes held in LDS (1024, or 512 when the keys take 128 KB)
-    int sc;               // super-chunk: boxes per NMS round (512, or 256 when the keys take 128 KB of LDS)
     float iou_thr;
     SupTest sup;          // the same decision as `!(iou <= iou_thr)`, division-free (see suppresses())
     int max_det;
@@ -191,6 +194,10 @@ struct K3Args {
     float *out_scores;
     int32_t *out_cls, *out_anchor, *out_cand, *out_counts, *out_ncand;
     int32_t *flags;
+    int32_t *irr;         // [batch] K2's "improper box" flag per image (read, then cleared for the next launch)
+    float rfac;           // centre-bin filter: a kept box can suppress a box of width w only if their centres are within rfac w
+                          // (+ rounding slack) in x; 0 = filter off (threshold below K3_BIN_MIN_THR)
+    float bin_scale[RVA_MAX_BATCH];      // K3_BINS / source width of the image
 };
 
 #ifdef RVA_K3_STAMPS
@@ -208,6 +215,8 @@ constexpr int K3_WAVES = K3_THREADS / 64;
 #endif
 constexpr int K3_NEWEST = RVA_K3_NEWEST;     // phase 1, stage A: the kept boxes every box of a round is tested against before the round is thinned out
 constexpr int K3_KBL = 1024;       // kept boxes held in LDS for phase 1 at most (K3Args::kbl; further ones are read back from out_boxes)
+constexpr int K3_BINS = 64;        // centre-x bins of the kept list (phase 1, see k3_nms)
+constexpr double K3_BIN_MIN_THR = 0.15;  // below it the centre distance bound is wider than three box widths: not worth a filter
 
 extern __shared__ __attribute__((aligned(16))) unsigned char k3_smem[];
 
@@ -280,10 +289,11 @@ __device__ __forceinline__ void k3_sort(unsigned long long *keys, int tid)
 }
 
 // output row `pos` of image b: kept box, its score / class / anchor, its index among the thresholded candidates in anchor order
+template <bool BOX = true>
 __device__ __forceinline__ void k3_emit(const K3Args &a, int b, int pos, const float4 kbx, int kan, const float *score, const uint32_t *bw, const int *wprefix)
 {
     const long o = (long)b * a.max_det + pos;
-    a.out_boxes[o] = kbx;
+    if (BOX) a.out_boxes[o] = kbx;
     a.out_scores[o] = score[kan];
     a.out_cls[o] = a.sp_cls[(long)b * a.A + kan];
     if (a.out_anchor) a.out_anchor[o] = kan;
@@ -296,20 +306,26 @@ __device__ __forceinline__ void k3_emit(const K3Args &a, int b, int pos, const f
 __global__ void __launch_bounds__(K3_THREADS) k3_nms(K3Args a)
 {
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int SC = a.sc, KBL = a.kbl;
-    // LDS carve (all offsets multiples of 16)
-    unsigned long long *keys = (unsigned long long *)k3_smem;                 // [kcap]
-    size_t off = (size_t)a.kcap * 8;
-    float4 *kb = (float4 *)(k3_smem + off); off += (size_t)(KBL + 8) * 16;   // kept boxes so far; the rest stays all-zero (such a box suppresses nothing a kept box would not)
-    float4 *sv_box = (float4 *)(k3_smem + off); off += (size_t)SC * 16;     // survivors of phase 1, in order
-    int *sv_j = (int *)(k3_smem + off); off += (size_t)SC * 4;              // their position in the sorted list
-    int *kj = (int *)(k3_smem + off); off += (size_t)KBL * 4;            // kept boxes so far: position in the sorted list
-    float *ka = (float *)(k3_smem + off); off += (size_t)(KBL + 8) * 4;     // their areas (zero past the list, like the boxes)
-    unsigned long long *smask = (unsigned long long *)(k3_smem + off); off += (size_t)SC * (SC / 64) * 8;   // [SC][SC/64]
+    // LDS carve, fixed part (all offsets multiples of 16); the large arrays follow once the number of candidates is known
+    size_t off = 0;
     int *wprefix = (int *)(k3_smem + off); off += (((size_t)a.nwords * 4 + 15) & ~(size_t)15);             // [nwords]
     int *wave_tot = (int *)(k3_smem + off); off += 64;                       // [16]
     unsigned long long *half_alive = (unsigned long long *)(k3_smem + off); off += 128;   // [16] phase-1 ballots of the two halves
-    int *s_ctl = (int *)(k3_smem + off);                                     // [0] survivors, [1] kept so far, [2] scan carry, [3] K
+    int *s_ctl = (int *)(k3_smem + off); off += 64;                          // [0] survivors, [1] kept so far, [2] scan carry, [3] K
+    int *binstart = (int *)(k3_smem + off); off += (K3_BINS + 4) * 4;        // [K3_BINS + 1] first list position of a centre-x bin
+    int *bincnt = (int *)(k3_smem + off); off += K3_BINS * 4;                // [K3_BINS]
+    // Centre-bin filter of phase 1 (binned mode).  With proper boxes (x1 <= x2, y1 <= y2) a kept box B suppresses a box A only if
+    // the float32 quotient exceeds thr, which needs  overlap_x >= thr' max(wA, wB)  (thr' = thr less a few ulps: inter <= overlap_x
+    // min(hA, hB), union >= the larger area >= max(wA, wB) min(hA, hB)); with  |cA - cB| <= (wA + wB) / 2 - overlap_x  and
+    // wB <= wA / thr'  that bounds the centre distance by  wA max(1 - thr', 1 / (2 thr') - 1 / 2).  a.rfac is that factor with 1 %
+    // on top, the radius gets an absolute slack far above the rounding of the centres: no suppressor is ever outside
+    // [cA - R, cA + R].  The kept list is therefore kept SORTED BY CENTRE-X BIN (a counting sort at the start of every round; the
+    // keep order lives in kj / out_boxes) and a box scans the slice of its bins only -- a real kept box that happens to sit in
+    // the slice's alignment padding and hits is a true suppressor too, so nothing is masked.  Images with an improper box (K2
+    // flags them) or a threshold below K3_BIN_MIN_THR take the unsorted list.
+    const bool binned = a.rfac > 0.f && a.irr[b] == 0;
+    const float bscale = a.bin_scale[b];
+    auto xbin = [&](float x) { const int v = (int)floorf(x * bscale); return v < 0 ? 0 : (v > K3_BINS - 1 ? K3_BINS - 1 : v); };
 
 #ifdef RVA_K3_STAMPS
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
@@ -317,8 +333,12 @@ __global__ void __launch_bounds__(K3_THREADS) k3_nms(K3Args a)
     // ---- candidates = set bits of the pass bitmap: exclusive prefix of the word popcounts (512 words per round)
     const uint32_t *bw = a.bits + (long)b * a.nwords;
     if (tid == 0) { s_ctl[1] = 0; s_ctl[2] = 0; }
-    for (int i = tid; i < KBL + 8; i += K3_THREADS) { kb[i] = make_float4(0.f, 0.f, 0.f, 0.f); ka[i] = 0.f; }
+    if (tid < K3_BINS) bincnt[tid] = 0;
     __syncthreads();
+    if (tid == 0) {
+        a.irr[b] = 0;                                             // every thread has read it: clean for the next launch
+        if (binned) atomicAdd(a.flags + 1 + RVA_MAX_BATCH, 1);    // rva_post_filter_stats()
+    }
     for (int w0 = 0; w0 < a.nwords; w0 += K3_THREADS) {
         const int w = w0 + tid;
         const int c = w < a.nwords ? __popc(bw[w]) : 0;
@@ -349,6 +369,17 @@ __global__ void __launch_bounds__(K3_THREADS) k3_nms(K3Args a)
     }
     int Kpad = K3_THREADS;
     while (Kpad < K) Kpad <<= 1;
+    // The large arrays.  Up to 8192 candidates (64 KB of keys) leave room for rounds of 512 boxes and 1024 kept boxes in LDS; only an
+    // image with more (128 KB of keys) falls back to rounds of 256 / 512 kept boxes -- the launch reserves LDS for either.
+    const int SC = Kpad <= 8192 ? 512 : 256, KBL = Kpad <= 8192 ? K3_KBL : K3_KBL / 2;
+    unsigned long long *keys = (unsigned long long *)(k3_smem + off); off += (size_t)Kpad * 8;                // [Kpad]
+    float4 *kb = (float4 *)(k3_smem + off); off += (size_t)(KBL + 8) * 16;   // kept boxes so far; the rest stays all-zero (such a box suppresses nothing a kept box would not)
+    float4 *sv_box = (float4 *)(k3_smem + off); off += (size_t)SC * 16;     // survivors of phase 1, in order
+    int *sv_j = (int *)(k3_smem + off); off += (size_t)SC * 4;              // their position in the sorted list
+    int *kj = (int *)(k3_smem + off); off += (size_t)KBL * 4;               // kept boxes so far: position in the sorted list
+    float *ka = (float *)(k3_smem + off); off += (size_t)(KBL + 8) * 4;     // their areas (zero past the list, like the boxes)
+    unsigned long long *smask = (unsigned long long *)(k3_smem + off);      // [SC][SC/64]
+    for (int i = tid; i < KBL + 8; i += K3_THREADS) { kb[i] = make_float4(0.f, 0.f, 0.f, 0.f); ka[i] = 0.f; }
     const float *score = a.sp_score + (long)b * a.A;
     const float4 *box = a.sp_box + (long)b * a.A;
     for (int i = K + tid; i < Kpad; i += K3_THREADS) keys[i] = ~0ull;
@@ -400,11 +431,68 @@ __global__ void __launch_bounds__(K3_THREADS) k3_nms(K3Args a)
         bool alive = valid;
         const int nk = s_ctl[1] < a.max_det ? s_ctl[1] : a.max_det;
         const int nk_lds = nk < KBL ? nk : KBL;
+        if (binned && nk_lds > 0) {
+            // ---- the kept list into centre-x bin order: a counting sort in place -- every thread holds its entry in registers
+            // across the barrier, so nothing is overwritten before it was read; every wave scans the 64 bin counts for itself
+            const bool mine = tid < nk_lds, wave_in = (tid & ~63) < nk_lds;      // waves without an entry only keep the barriers
+            float4 mb = zero4;
+            float ma = 0.f;
+            int mbin = 0, slot = 0;
+            if (wave_in) {
+                if (mine) { mb = kb[tid]; ma = ka[tid]; }
+                mbin = xbin((mb.x + mb.z) * 0.5f);
+                if (mine) slot = atomicAdd(&bincnt[mbin], 1);
+            }
+            __syncthreads();
+            if (wave_in) {
+                const int c = bincnt[lane];
+                int incl = c;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int t = __shfl_up(incl, o);
+                    if (lane >= o) incl += t;
+                }
+                const int dst = __shfl(incl - c, mbin) + slot;
+                if (wave == 0) {
+                    binstart[lane] = incl - c;
+                    if (lane == 63) binstart[64] = incl;
+                }
+                if (mine) { kb[dst] = mb; ka[dst] = ma; }
+            }
+            __syncthreads();
+            if (tid < K3_BINS) bincnt[tid] = 0;                     // for the next round (many barriers away)
+            K3_STAMP(6);
+        }
+        if (binned) {
+            // ---- phase 1, binned, stage A: the kept boxes of the box's own centre-x bin and its two neighbours (a box's suppressor is
+            // usually the head of its own cluster: nearly the same centre), four per step (per-lane addresses), the two threads of a
+            // box take alternate groups of four.  Stage B below: the survivors against their whole slice.
+            const float cx = (bx.x + bx.z) * 0.5f;
+            const int bc = xbin(cx);
+            const int s0 = nk_lds > 0 ? binstart[bc > 0 ? bc - 1 : 0] & ~3 : 0, s1 = nk_lds > 0 ? binstart[(bc < K3_BINS - 1 ? bc + 1 : bc) + 1] : 0;
+            for (int i = s0 + 4 * half; ; i += 8) {
+                if (!__any(alive && i < s1)) break;
+                const int ii = i < KBL ? i : KBL;                  // lanes past their slice idle on the zero padding
+                float4 k4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) k4[u] = kb[ii + u];
+                const float4 a4 = *reinterpret_cast<const float4 *>(ka + ii);
+                const float ar[4] = {a4.x, a4.y, a4.z, a4.w};
+                bool hit = false, unsure = false;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) hit |= suppresses_fast(k4[u], ar[u], bx, area_b, a.sup, unsure);     // detector.py:373
+                if (__any(unsure)) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) hit |= suppresses(k4[u], ar[u], bx, area_b, a.sup);
+                }
+                alive = alive && !hit;
+            }
+        }
         // Stage A: the K3_NEWEST most recently kept boxes (a box's suppressor scored only a little higher than the box itself,
         // so it is usually among them).  Four kept boxes per step, branch-free: the (broadcast) LDS reads and the four tests
         // of a step overlap, one early-exit test per step; reads past the list find all-zero boxes.
-        const int lo = nk_lds > K3_NEWEST ? (nk_lds - K3_NEWEST) & ~7 : 0;        // stage B takes the kept boxes [0, lo)
-        for (int i = lo + 4 * half; i < nk_lds; i += 8) {
+        const int lo = !binned && nk_lds > K3_NEWEST ? (nk_lds - K3_NEWEST) & ~7 : 0;        // stage B takes the kept boxes [0, lo)
+        for (int i = lo + 4 * half; !binned && i < nk_lds; i += 8) {
             if (!__any(alive)) break;
             float4 k4[4];
 #pragma unroll
@@ -435,8 +523,19 @@ __global__ void __launch_bounds__(K3_THREADS) k3_nms(K3Args a)
         alive = half == 0 && ((am >> lane) & 1ull);
         if (lane == 0) wave_tot[wave] = half == 0 ? __popcll(am) : 0;
         __syncthreads();
-        int so = 0, ns = 0;
-        for (int q = 0; q < K3_WAVES / 2; ++q) { if (q < wave) so += wave_tot[q]; ns += wave_tot[q]; }
+        int so, ns;
+        {   // exclusive prefix / total of the eight wave counts: one LDS read, a scan in the wave
+            const int c = lane < K3_WAVES / 2 ? wave_tot[lane] : 0;
+            int incl = c;
+#pragma unroll
+            for (int o = 1; o < K3_WAVES / 2; o <<= 1) {
+                const int t = __shfl_up(incl, o);
+                if (lane >= o) incl += t;
+            }
+            so = __shfl(incl - c, wave & (K3_WAVES / 2 - 1));
+            ns = __shfl(incl, K3_WAVES / 2 - 1);
+            if (wave >= K3_WAVES / 2) so = 0;
+        }
         if (alive) {
             const int sidx = so + __popcll(am & ((1ull << lane) - 1ull));
             sv_box[sidx] = bx;
@@ -445,13 +544,36 @@ __global__ void __launch_bounds__(K3_THREADS) k3_nms(K3Args a)
         __syncthreads();
         // Stage B: what is left (a fraction) against the older kept boxes [0, lo), all 1024 threads again: thread t takes box
         // t mod mp (mp = the count padded to whole waves) and every (1024 / mp)-th group of four kept boxes; a hit marks the box.
-        if (lo > 0 && ns > 0) {                                   // uniform
+        if ((binned ? nk_lds > 0 : lo > 0) && ns > 0) {           // uniform
             const int mp = (ns + 63) & ~63, parts = K3_THREADS / mp;
             const int part = tid / mp, bi = tid - part * mp;      // part is the same for a whole wave
             bool open = part < parts && bi < ns;
             const float4 ob = open ? sv_box[bi] : zero4;
             const float area_o = box_area(ob);
-            for (int i = 4 * part; i < lo; i += 4 * parts) {
+            if (binned) {                                         // the survivor's slice: every bin a suppressor's centre can lie in
+                const float cx = (ob.x + ob.z) * 0.5f;
+                const float rad = (ob.z - ob.x) * a.rfac + (ob.x + ob.z) * 1e-5f + 1e-2f;
+                const int s0 = binstart[xbin(cx - rad)] & ~3, s1 = binstart[xbin(cx + rad) + 1];
+                for (int i = s0 + 4 * part; ; i += 4 * parts) {
+                    if (!__any(open && i < s1)) break;
+                    const int ii = i < KBL ? i : KBL;
+                    float4 k4[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) k4[u] = kb[ii + u];
+                    const float4 a4 = *reinterpret_cast<const float4 *>(ka + ii);
+                    const float ar[4] = {a4.x, a4.y, a4.z, a4.w};
+                    bool hit = false, unsure = false;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) hit |= suppresses_fast(k4[u], ar[u], ob, area_o, a.sup, unsure);
+                    if (__any(unsure)) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) hit |= suppresses(k4[u], ar[u], ob, area_o, a.sup);
+                    }
+                    if (open && hit) sv_j[bi] = -1;
+                    open = open && !hit;
+                }
+            }
+            for (int i = 4 * part; !binned && i < lo; i += 4 * parts) {
                 if (!__any(open)) break;
                 float4 k4[4];
 #pragma unroll
@@ -476,8 +598,18 @@ __global__ void __launch_bounds__(K3_THREADS) k3_nms(K3Args a)
             const unsigned long long lm = __ballot(sj >= 0);
             if (lane == 0) wave_tot[wave] = __popcll(lm);
             __syncthreads();
-            int so2 = 0, ns2 = 0;
-            for (int q = 0; q < K3_WAVES / 2; ++q) { if (q < wave) so2 += wave_tot[q]; ns2 += wave_tot[q]; }
+            int so2, ns2;
+            {
+                const int c = lane < K3_WAVES / 2 ? wave_tot[lane] : 0;
+                int incl = c;
+#pragma unroll
+                for (int o = 1; o < K3_WAVES / 2; o <<= 1) {
+                    const int t = __shfl_up(incl, o);
+                    if (lane >= o) incl += t;
+                }
+                so2 = __shfl(incl - c, wave & (K3_WAVES / 2 - 1));
+                ns2 = __shfl(incl, K3_WAVES / 2 - 1);
+            }
             if (sj >= 0) {
                 const int sidx = so2 + __popcll(lm & ((1ull << lane) - 1ull));
                 sv_box[sidx] = sb;
@@ -551,7 +683,10 @@ __global__ void __launch_bounds__(K3_THREADS) k3_nms(K3Args a)
                 if ((kept >> lane) & 1ull) {
                     const int pos = out0 + __popcll(kept & ((1ull << lane) - 1ull));
                     const float4 kbx = sv_box[r];
-                    if (pos < KBL) { kb[pos] = kbx; ka[pos] = box_area(kbx); kj[pos] = sv_j[r]; }   // its output row is written after the last round
+                    if (pos < KBL) {                               // the rest of its output row is written after the last round
+                        kb[pos] = kbx; ka[pos] = box_area(kbx); kj[pos] = sv_j[r];
+                        if (pos < a.max_det) a.out_boxes[(long)b * a.max_det + pos] = kbx;       // (the LDS list does not stay in keep order)
+                    }
                     else if (pos < a.max_det) k3_emit(a, b, pos, kbx, (int)(uint32_t)keys[sv_j[r]], score, bw, wprefix);
                     if (pos >= a.max_det) atomicOr(a.flags, 1);
                 }
@@ -567,7 +702,7 @@ __global__ void __launch_bounds__(K3_THREADS) k3_nms(K3Args a)
     {
         int n = s_ctl[1] < a.max_det ? s_ctl[1] : a.max_det;
         n = n < KBL ? n : KBL;
-        for (int pos = tid; pos < n; pos += K3_THREADS) k3_emit(a, b, pos, kb[pos], (int)(uint32_t)keys[kj[pos]], score, bw, wprefix);
+        for (int pos = tid; pos < n; pos += K3_THREADS) k3_emit<false>(a, b, pos, zero4, (int)(uint32_t)keys[kj[pos]], score, bw, wprefix);
     }
     if (tid == 0) {
         const int n = s_ctl[1];
@@ -614,11 +749,11 @@ extern "C" int rva_postprocess_batch(rva_ctx *ctx, const void *raw, int raw_dtyp
     int kcap = K3_THREADS;
     while (kcap < A && kcap < 16384) kcap <<= 1;
     const int nwords = rva_ceil_div(A, 32);
-    const int sc = kcap <= 8192 ? 512 : 256;                       // 128 KB of keys leave room for a 256-box round only (sc <= 512:
-                                                                   // two threads per box in phase 1)
-    const int kbl = kcap <= 8192 ? K3_KBL : K3_KBL / 2;
-    const size_t smem = (size_t)kcap * 8 + (size_t)(kbl + 8) * 20 + (size_t)kbl * 4 + (size_t)sc * 20 + (size_t)sc * (sc / 64) * 8 +
-                        (((size_t)nwords * 4 + 15) & ~(size_t)15) + 64 + 128 + 64;
+    // LDS: the fixed arrays + the larger of the kernel's two layouts (see k3_nms: chosen per image from its candidate count)
+    auto layout = [](size_t keys, size_t kbl, size_t sc) { return keys * 8 + (kbl + 8) * 20 + kbl * 4 + sc * 20 + sc * (sc / 64) * 8; };
+    const size_t fixed = (((size_t)nwords * 4 + 15) & ~(size_t)15) + 64 + 128 + 64 + (K3_BINS + 4) * 4 + K3_BINS * 4;
+    size_t smem = fixed + layout(kcap < 8192 ? kcap : 8192, K3_KBL, 512);
+    if (kcap > 8192 && fixed + layout(kcap, K3_KBL / 2, 256) > smem) smem = fixed + layout(kcap, K3_KBL / 2, 256);
     if (smem > 160 * 1024) return rva_fail(ctx, RVA_ERR_CAPACITY, "post-process: %d anchors need %zu B of LDS", A, smem);
     RVA_HIP(ctx, rva_func_smem((const void *)k3_nms, smem));
 
@@ -642,6 +777,7 @@ extern "C" int rva_postprocess_batch(rva_ctx *ctx, const void *raw, int raw_dtyp
         }
         k2.sp_box = (float4 *)ctx->sp_box; k2.sp_score = ctx->sp_score; k2.sp_cls = ctx->sp_cls;
         k2.bits = ctx->cand_bits; k2.nwords = nwords;
+        k2.irr = ctx->post_flags + 1;
         dim3 g2(rva_ceil_div(A, 256), nb);
         if (raw_dtype == RVA_F16) k2_decode<__half><<<g2, 256, 0, stream>>>(k2);
         else k2_decode<float><<<g2, 256, 0, stream>>>(k2);
@@ -649,7 +785,7 @@ extern "C" int rva_postprocess_batch(rva_ctx *ctx, const void *raw, int raw_dtyp
         K3Args k3{};
         k3.sp_box = (const float4 *)ctx->sp_box; k3.sp_score = ctx->sp_score; k3.sp_cls = ctx->sp_cls;
         k3.bits = ctx->cand_bits;
-        k3.nwords = nwords; k3.A = A; k3.kcap = kcap; k3.sc = sc; k3.kbl = kbl;
+        k3.nwords = nwords; k3.A = A; k3.kcap = kcap;
         k3.iou_thr = (float)iou_thr;
         {   // where rounding leaves thr: midpoint to the next float above, a tie goes to the even mantissa
             const float t = (float)iou_thr;
@@ -668,9 +804,31 @@ extern "C" int rva_postprocess_batch(rva_ctx *ctx, const void *raw, int raw_dtyp
         k3.out_counts = out_counts + b0;
         k3.out_ncand = out_ncand ? out_ncand + b0 : nullptr;
         k3.flags = ctx->post_flags;
+        k3.irr = ctx->post_flags + 1;
+        {   // centre-bin filter (see k3_nms): the distance factor for this threshold, 1 % on top
+            const double t = (double)(float)iou_thr * (1.0 - 1e-6);
+            k3.rfac = std::isfinite(t) && t >= K3_BIN_MIN_THR && t <= 0.999 && !getenv("RVA_K3_NOBINS")
+                          ? (float)((t >= 0.5 ? 1.0 - t : 0.5 / t - 0.5) * 1.01) : 0.f;
+            for (int i = 0; i < nb; ++i) {
+                const rva_letterbox &m = metas[n_metas == 1 ? 0 : b0 + i];
+                k3.bin_scale[i] = m.src_w > 0 ? (float)K3_BINS / (float)m.src_w : 1.f;
+            }
+        }
         k3_nms<<<nb, K3_THREADS, smem, stream>>>(k3);
     }
     RVA_HIP(ctx, hipGetLastError());
+    return RVA_OK;
+}
+
+extern "C" int rva_post_filter_stats(rva_ctx *ctx, rva_stream_t stream_, int *binned_images)
+{
+    if (!ctx || !binned_images) return RVA_ERR_ARG;
+    hipStream_t stream = (hipStream_t)stream_;
+    int32_t v = 0;
+    RVA_HIP(ctx, hipMemcpyAsync(&v, ctx->post_flags + 1 + RVA_MAX_BATCH, sizeof v, hipMemcpyDeviceToHost, stream));
+    RVA_HIP(ctx, hipMemsetAsync(ctx->post_flags + 1 + RVA_MAX_BATCH, 0, sizeof v, stream));
+    RVA_HIP(ctx, hipStreamSynchronize(stream));
+    *binned_images = v;
     return RVA_OK;
 }
 

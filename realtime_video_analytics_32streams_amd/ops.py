@@ -391,6 +391,14 @@ def post_status(ctx: Optional[N.Context] = None) -> int:
     return f.value
 
 
+def post_filter_stats(ctx: Optional[N.Context] = None) -> int:
+    """Images since the last call whose NMS went through K3's centre-bin filter (diagnostic, ``rva_post_filter_stats``)."""
+    ctx = ctx or context()
+    f = C.c_int()
+    ctx.check(N.lib().rva_post_filter_stats(ctx.handle, _stream_ptr(), C.byref(f)), "rva_post_filter_stats")
+    return f.value
+
+
 # ------------------------------------------------------------------------------------------ K4
 class DeviceTracker:
     """All per-stream track tables of this process, resident in HBM (wraps ``rva_tracker``)."""

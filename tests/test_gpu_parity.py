@@ -168,6 +168,76 @@ def test_postprocess_suppression_decisions_at_the_threshold_boundary():
         assert 0 < n_sup < len(a)                                     # both outcomes occurred
 
 
+@pytest.mark.parametrize("src", [(640, 640), (1920, 1080)])
+def test_postprocess_centre_bin_filter_finds_every_suppressor(src):
+    """K3 scans, for a box, only the kept boxes whose centre-x bin lies within the distance at which a suppressor can sit
+    (rva_postprocess.hip, "centre-bin filter").  Scenes built against that bound: per threshold, hundreds of (kept, victim)
+    pairs at the LARGEST centre distance the geometry allows for an IoU just above the threshold -- victim much narrower than
+    its suppressor (flush left / flush right), much wider, equal widths shifted -- next to the same constructions just below
+    the threshold (victim survives), spread over the whole width with filler boxes so that the kept list spans every bin and
+    the slices matter.  Every image must equal the oracle's sequential NMS, and the diagnostic counter must say the filter ran;
+    an image with one improper candidate (negative raw width) steps aside to the unfiltered scan -- same answer -- and the flag
+    does not leak into the next launch."""
+    rng = np.random.default_rng(17)
+    f32 = np.float32
+    sw, sh = src
+    lb = N.letterbox(sw, sh, 640, 640)
+    ops.post_filter_stats()
+    for thr in (0.2, 0.3, 0.45, 0.5, 0.7, 0.9):
+        heads = np.zeros((8, 84, 2048), f32)
+        for img in range(8):
+            k = 0
+            def put(cx, cy, w, h, score):
+                nonlocal k
+                heads[img, 0:4, k] = (cx, cy, w, h); heads[img, 4, k] = 1.0; heads[img, 5 + (k % 3), k] = score
+                k += 1
+            y0, y1 = (150.0, 490.0) if sw == 1920 else (10.0, 630.0)          # inside the letterboxed content
+            for j in range(60):
+                c = 1.03 if j % 2 == 0 else 0.97                               # IoU = thr c: suppressed / survives
+                kind = j % 4 if thr * c < 0.95 else 3
+                h = float(rng.uniform(12, 30)); cy = float(rng.uniform(y0 + 20, y1 - 20))
+                x0 = float(rng.uniform(5, 400)); score = float(rng.uniform(0.5, 0.9))
+                if kind == 0:            # kept = wide, victim = narrow, flush left: IoU = w / W
+                    W = float(rng.uniform(60, 200)); w = W * thr * c
+                    put(x0 + W / 2, cy, W, h, score); put(x0 + w / 2, cy, w, h, score - 0.2)
+                elif kind == 1:          # the same, flush right
+                    W = float(rng.uniform(60, 200)); w = W * thr * c
+                    put(x0 + W / 2, cy, W, h, score); put(x0 + W - w / 2, cy, w, h, score - 0.2)
+                elif kind == 2:          # kept = narrow, victim = wide
+                    W = float(rng.uniform(60, 200)); w = W * thr * c
+                    put(x0 + w / 2, cy, w, h, score); put(x0 + W / 2, cy, W, h, score - 0.2)
+                else:                    # equal widths, shifted: IoU = (w - d) / (w + d)
+                    w = float(rng.uniform(30, 150)); d = w * (1 - thr * c) / (1 + thr * c)
+                    put(x0 + w / 2, cy, w, h, score); put(x0 + d + w / 2, cy, w, h, score - 0.2)
+            for j in range(300):         # filler: small boxes everywhere (most are kept: the list covers every bin)
+                put(float(rng.uniform(10, 630)), float(rng.uniform(y0, y1)), float(rng.uniform(4, 12)), float(rng.uniform(4, 12)), float(rng.uniform(0.3, 0.95)))
+        t = torch.from_numpy(heads).to(DEV)
+        res = ops.postprocess(t, 0.25, thr, None, [lb]).to_host()
+        assert ops.post_status() == 0 and ops.post_filter_stats() == 8, thr
+        n_kept = []
+        for i, got in enumerate(res):
+            want = orc.postprocess(heads[i], 0.25, thr, None, (sw, sh))
+            assert got["n"] == want["n"] and np.array_equal(got["anchor"], want["anchor"]), (thr, i)
+            assert np.array_equal(got["boxes"], want["boxes"]) and np.array_equal(got["conf"], want["conf"])
+            n_kept.append(got["n"])
+        assert min(n_kept) > 200                                               # a long kept list: slices, not the whole list
+        # one improper candidate in image 3: that image alone takes the unfiltered scan
+        bad = heads.copy()
+        bad[3, 0:4, 2040] = (320.0, 320.0, -20.0, 10.0); bad[3, 4, 2040] = 1.0; bad[3, 5, 2040] = 0.99
+        res = ops.postprocess(torch.from_numpy(bad).to(DEV), 0.25, thr, None, [lb]).to_host()
+        assert ops.post_filter_stats() == 7
+        for i, got in enumerate(res):
+            want = orc.postprocess(bad[i], 0.25, thr, None, (sw, sh))
+            assert got["n"] == want["n"] and np.array_equal(got["anchor"], want["anchor"]), ("improper", thr, i)
+        ops.postprocess(t, 0.25, thr, None, [lb])
+        assert ops.post_filter_stats() == 8                                    # the flag was cleared
+    res = ops.postprocess(t, 0.25, 0.1, None, [lb]).to_host()                  # below the filter's threshold range: unfiltered
+    assert ops.post_filter_stats() == 0
+    for i, got in enumerate(res):
+        want = orc.postprocess(heads[i], 0.25, 0.1, None, (sw, sh))
+        assert got["n"] == want["n"] and np.array_equal(got["anchor"], want["anchor"])
+
+
 def test_postprocess_properties_at_full_size():
     """Size-independent properties on the [32,84,8400] workload: idempotence of NMS on its own
     output, descending scores, every kept pair has IoU <= thr."""

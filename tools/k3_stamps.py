@@ -1,7 +1,7 @@
 """Where k3_nms spends its cycles under load: builds a private librva with -DRVA_K3_STAMPS (s_memtime sums per phase, thread 0
 of every block) into tools/_dbg/ and runs the post-process on the load sweep's synthetic heads.
 usage: python tools/k3_stamps.py [--build-only] [D]      phases: 0 candidates+keys | 1 sort | 2 phase 1 (vs kept list) |
-3 survivor compaction | 4 phase 2a (suppression matrix) | 5 phase 2b (greedy walk + outputs)"""
+3 survivor compactions + stage B | 4 phase 2a (suppression matrix) | 5 phase 2b (greedy walk + outputs)"""
 import ctypes as C, os, subprocess, sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]
@@ -28,8 +28,8 @@ for _ in range(5):
 torch.cuda.synchronize()
 buf = (C.c_ulonglong * (64 * 8))()
 assert N.lib().rva_dbg_k3_stamps(buf) == 0
-st = np.frombuffer(buf, dtype=np.uint64).reshape(64, 8)[:S, :6].astype(np.float64)
-names = ["candidates+keys", "sort", "phase 1", "compaction", "phase 2a", "phase 2b"]
+st = np.frombuffer(buf, dtype=np.uint64).reshape(64, 8)[:S, :7].astype(np.float64)
+names = ["candidates+keys", "sort", "phase 1 stage A", "compactions+stage B", "phase 2a", "phase 2b", "kept list re-bin"]
 print(f"D={D}: candidates/frame {float(post.ncand.float().mean()):.0f} kept/frame {float(post.counts.float().mean()):.1f}; cycles of thread 0, mean over {S} blocks")
 for i, n in enumerate(names):
     print(f"  {n:18s} {st[:, i].mean():10.0f}  ({100 * st[:, i].mean() / st.sum(1).mean():5.1f} %)")
