@@ -195,6 +195,7 @@ struct K3Args {
     int32_t *out_cls, *out_anchor, *out_cand, *out_counts, *out_ncand;
     int32_t *flags;
     int32_t *irr;         // [batch] K2's "improper box" flag per image (read, then cleared for the next launch)
+    int bitonic_upto;     // experiment switch (RVA_K3_BITONIC_UPTO): candidate counts up to this take the bitonic network instead of the radix sort
     float rfac;           // centre-bin filter: a kept box can suppress a box of width w only if their centres are within rfac w
                           // (+ rounding slack) in x; 0 = filter off (threshold below K3_BIN_MIN_THR)
     float bin_scale[RVA_MAX_BATCH];      // K3_BINS / source width of the image
@@ -216,6 +217,7 @@ constexpr int K3_WAVES = K3_THREADS / 64;
 constexpr int K3_NEWEST = RVA_K3_NEWEST;     // phase 1, stage A: the kept boxes every box of a round is tested against before the round is thinned out
 constexpr int K3_KBL = 1024;       // kept boxes held in LDS for phase 1 at most (K3Args::kbl; further ones are read back from out_boxes)
 constexpr int K3_BINS = 64;        // centre-x bins of the kept list (phase 1, see k3_nms)
+constexpr int K3_BIN_MIN_KEPT = 96; // kept boxes from which a round sorts the list into bins
 constexpr double K3_BIN_MIN_THR = 0.15;  // below it the centre distance bound is wider than three box widths: not worth a filter
 
 extern __shared__ __attribute__((aligned(16))) unsigned char k3_smem[];
@@ -288,6 +290,77 @@ __device__ __forceinline__ void k3_sort(unsigned long long *keys, int tid)
     __syncthreads();
 }
 
+// Stable LSD radix sort of the K valid keys by their high 32 bits (the score part), 8 bits per pass, src -> dst -> src ...: four
+// passes end in `a`.  The keys were written in anchor order and equal scores keep it, so the result is the bitonic sort's total
+// order (score descending, anchor ascending) at a third of its vector instructions.  Wave w owns elements [w 64 E, (w + 1) 64 E),
+// slot e of lane l is element w 64 E + 64 e + l: the stable order inside a wave is (slot, lane).  Per pass: a wave counts its
+// digits slot by slot (lanes with the same digit find one another with eight ballots; the rank of an element among them is a
+// popcount below the lane; the lowest lane of a group adds the group to the wave's counter), 256 threads turn the counters
+// hist[wave][digit] into start positions in (digit, wave) order, and every element goes to start + its rank in the wave.
+template <int E>
+__device__ __forceinline__ void k3_radix(unsigned long long *a, unsigned long long *b2, int *hist, int *wtot, int K, int tid)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+    unsigned long long *src = a, *dst = b2;
+    int *wh = hist + wave * 256;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int sh = 32 + 8 * pass;
+        for (int i = tid; i < K3_WAVES * 256; i += K3_THREADS) hist[i] = 0;
+        __syncthreads();
+        unsigned long long v[E];
+        int rk[E], dg[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int idx = wave * 64 * E + e * 64 + lane;
+            const bool in = idx < K;
+            v[e] = in ? src[idx] : ~0ull;
+            const int d = (int)(v[e] >> sh) & 255;
+            dg[e] = d;
+            unsigned long long m = __ballot(in);
+#pragma unroll
+            for (int bit = 0; bit < 8; ++bit) {
+                const bool one = (d >> bit) & 1;
+                const unsigned long long bb = __ballot(in && one);
+                m &= one ? bb : ~bb;
+            }
+            const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            const int old = in ? wh[d] : 0;
+            rk[e] = old + below;
+            if (in && below == 0) wh[d] = old + __popcll(m);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");          // the next slot reads what this one's group leaders wrote
+            __builtin_amdgcn_wave_barrier();
+        }
+        __syncthreads();
+        int c[K3_WAVES], run = 0, incl = 0;
+        if (tid < 256) {
+#pragma unroll
+            for (int w = 0; w < K3_WAVES; ++w) { const int t = hist[w * 256 + tid]; c[w] = run; run += t; }
+            incl = run;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(incl, o);
+                if (lane >= o) incl += t;
+            }
+            if (lane == 63) wtot[wave] = incl;
+        }
+        __syncthreads();
+        if (tid < 256) {
+            int base = incl - run;
+            for (int q = 0; q < wave; ++q) base += wtot[q];
+#pragma unroll
+            for (int w = 0; w < K3_WAVES; ++w) hist[w * 256 + tid] = base + c[w];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int idx = wave * 64 * E + e * 64 + lane;
+            if (idx < K) dst[wh[dg[e]] + rk[e]] = v[e];
+        }
+        __syncthreads();
+        unsigned long long *t = src; src = dst; dst = t;
+    }
+}
+
 // output row `pos` of image b: kept box, its score / class / anchor, its index among the thresholded candidates in anchor order
 template <bool BOX = true>
 __device__ __forceinline__ void k3_emit(const K3Args &a, int b, int pos, const float4 kbx, int kan, const float *score, const uint32_t *bw, const int *wprefix)
@@ -319,7 +392,8 @@ __global__ void __launch_bounds__(K3_THREADS) k3_nms(K3Args a)
     // min(hA, hB), union >= the larger area >= max(wA, wB) min(hA, hB)); with  |cA - cB| <= (wA + wB) / 2 - overlap_x  and
     // wB <= wA / thr'  that bounds the centre distance by  wA max(1 - thr', 1 / (2 thr') - 1 / 2).  a.rfac is that factor with 1 %
     // on top, the radius gets an absolute slack far above the rounding of the centres: no suppressor is ever outside
-    // [cA - R, cA + R].  The kept list is therefore kept SORTED BY CENTRE-X BIN (a counting sort at the start of every round; the
+    // [cA - R, cA + R].  The kept list is therefore kept SORTED BY CENTRE-X BIN (a counting sort at the start of every round once it holds
+    // K3_BIN_MIN_KEPT boxes; the
     // keep order lives in kj / out_boxes) and a box scans the slice of its bins only -- a real kept box that happens to sit in
     // the slice's alignment padding and hits is a true suppressor too, so nothing is masked.  Images with an improper box (K2
     // flags them) or a threshold below K3_BIN_MIN_THR take the unsorted list.
@@ -379,7 +453,6 @@ __global__ void __launch_bounds__(K3_THREADS) k3_nms(K3Args a)
     int *kj = (int *)(k3_smem + off); off += (size_t)KBL * 4;               // kept boxes so far: position in the sorted list
     float *ka = (float *)(k3_smem + off); off += (size_t)(KBL + 8) * 4;     // their areas (zero past the list, like the boxes)
     unsigned long long *smask = (unsigned long long *)(k3_smem + off);      // [SC][SC/64]
-    for (int i = tid; i < KBL + 8; i += K3_THREADS) { kb[i] = make_float4(0.f, 0.f, 0.f, 0.f); ka[i] = 0.f; }
     const float *score = a.sp_score + (long)b * a.A;
     const float4 *box = a.sp_box + (long)b * a.A;
     for (int i = K + tid; i < Kpad; i += K3_THREADS) keys[i] = ~0ull;
@@ -399,13 +472,20 @@ __global__ void __launch_bounds__(K3_THREADS) k3_nms(K3Args a)
     }
     __syncthreads();
     K3_STAMP(0);
-    switch (Kpad / K3_THREADS) {
-    case 1: k3_sort<1>(keys, tid); break;
-    case 2: k3_sort<2>(keys, tid); break;
-    case 4: k3_sort<4>(keys, tid); break;
+    // up to 4096 candidates: radix sort (second buffer, counters and wave totals borrow smask / kb / sv_box, all idle until the
+    // first round); more: the bitonic network in place
+    switch (Kpad <= a.bitonic_upto ? 64 + Kpad / K3_THREADS : Kpad / K3_THREADS) {
+    case 65: k3_sort<1>(keys, tid); break;
+    case 66: k3_sort<2>(keys, tid); break;
+    case 68: k3_sort<4>(keys, tid); break;
+    case 1: k3_radix<1>(keys, smask, (int *)kb, (int *)sv_box, K, tid); break;
+    case 2: k3_radix<2>(keys, smask, (int *)kb, (int *)sv_box, K, tid); break;
+    case 4: k3_radix<4>(keys, smask, (int *)kb, (int *)sv_box, K, tid); break;
     case 8: k3_sort<8>(keys, tid); break;
     default: k3_sort<16>(keys, tid); break;
     }
+    for (int i = tid; i < KBL + 8; i += K3_THREADS) { kb[i] = make_float4(0.f, 0.f, 0.f, 0.f); ka[i] = 0.f; }
+    __syncthreads();
 
     K3_STAMP(1);
     const int scw = SC >> 6;                                       // mask words per survivor row
@@ -431,7 +511,8 @@ __global__ void __launch_bounds__(K3_THREADS) k3_nms(K3Args a)
         bool alive = valid;
         const int nk = s_ctl[1] < a.max_det ? s_ctl[1] : a.max_det;
         const int nk_lds = nk < KBL ? nk : KBL;
-        if (binned && nk_lds > 0) {
+        const bool rb = binned && nk_lds >= K3_BIN_MIN_KEPT;      // a short kept list is scanned whole: sorting it costs more than it saves
+        if (rb) {
             // ---- the kept list into centre-x bin order: a counting sort in place -- every thread holds its entry in registers
             // across the barrier, so nothing is overwritten before it was read; every wave scans the 64 bin counts for itself
             const bool mine = tid < nk_lds, wave_in = (tid & ~63) < nk_lds;      // waves without an entry only keep the barriers
@@ -463,7 +544,7 @@ __global__ void __launch_bounds__(K3_THREADS) k3_nms(K3Args a)
             if (tid < K3_BINS) bincnt[tid] = 0;                     // for the next round (many barriers away)
             K3_STAMP(6);
         }
-        if (binned) {
+        if (rb) {
             // ---- phase 1, binned, stage A: the kept boxes of the box's own centre-x bin and its two neighbours (a box's suppressor is
             // usually the head of its own cluster: nearly the same centre), four per step (per-lane addresses), the two threads of a
             // box take alternate groups of four.  Stage B below: the survivors against their whole slice.
@@ -491,8 +572,8 @@ __global__ void __launch_bounds__(K3_THREADS) k3_nms(K3Args a)
         // Stage A: the K3_NEWEST most recently kept boxes (a box's suppressor scored only a little higher than the box itself,
         // so it is usually among them).  Four kept boxes per step, branch-free: the (broadcast) LDS reads and the four tests
         // of a step overlap, one early-exit test per step; reads past the list find all-zero boxes.
-        const int lo = !binned && nk_lds > K3_NEWEST ? (nk_lds - K3_NEWEST) & ~7 : 0;        // stage B takes the kept boxes [0, lo)
-        for (int i = lo + 4 * half; !binned && i < nk_lds; i += 8) {
+        const int lo = !rb && nk_lds > K3_NEWEST ? (nk_lds - K3_NEWEST) & ~7 : 0;        // stage B takes the kept boxes [0, lo)
+        for (int i = lo + 4 * half; !rb && i < nk_lds; i += 8) {
             if (!__any(alive)) break;
             float4 k4[4];
 #pragma unroll
@@ -544,13 +625,13 @@ __global__ void __launch_bounds__(K3_THREADS) k3_nms(K3Args a)
         __syncthreads();
         // Stage B: what is left (a fraction) against the older kept boxes [0, lo), all 1024 threads again: thread t takes box
         // t mod mp (mp = the count padded to whole waves) and every (1024 / mp)-th group of four kept boxes; a hit marks the box.
-        if ((binned ? nk_lds > 0 : lo > 0) && ns > 0) {           // uniform
+        if ((rb || lo > 0) && ns > 0) {           // uniform
             const int mp = (ns + 63) & ~63, parts = K3_THREADS / mp;
             const int part = tid / mp, bi = tid - part * mp;      // part is the same for a whole wave
             bool open = part < parts && bi < ns;
             const float4 ob = open ? sv_box[bi] : zero4;
             const float area_o = box_area(ob);
-            if (binned) {                                         // the survivor's slice: every bin a suppressor's centre can lie in
+            if (rb) {                                             // the survivor's slice: every bin a suppressor's centre can lie in
                 const float cx = (ob.x + ob.z) * 0.5f;
                 const float rad = (ob.z - ob.x) * a.rfac + (ob.x + ob.z) * 1e-5f + 1e-2f;
                 const int s0 = binstart[xbin(cx - rad)] & ~3, s1 = binstart[xbin(cx + rad) + 1];
@@ -573,7 +654,7 @@ __global__ void __launch_bounds__(K3_THREADS) k3_nms(K3Args a)
                     open = open && !hit;
                 }
             }
-            for (int i = 4 * part; !binned && i < lo; i += 4 * parts) {
+            for (int i = 4 * part; !rb && i < lo; i += 4 * parts) {
                 if (!__any(open)) break;
                 float4 k4[4];
 #pragma unroll
@@ -805,6 +886,7 @@ extern "C" int rva_postprocess_batch(rva_ctx *ctx, const void *raw, int raw_dtyp
         k3.out_ncand = out_ncand ? out_ncand + b0 : nullptr;
         k3.flags = ctx->post_flags;
         k3.irr = ctx->post_flags + 1;
+        k3.bitonic_upto = getenv("RVA_K3_BITONIC_UPTO") ? atoi(getenv("RVA_K3_BITONIC_UPTO")) : 0;
         {   // centre-bin filter (see k3_nms): the distance factor for this threshold, 1 % on top
             const double t = (double)(float)iou_thr * (1.0 - 1e-6);
             k3.rfac = std::isfinite(t) && t >= K3_BIN_MIN_THR && t <= 0.999 && !getenv("RVA_K3_NOBINS")
