@@ -9,21 +9,20 @@
 //   K2: one thread per anchor, coalesced along the anchor axis of [C, A] heads.  Anchors that pass write box / score /
 //       class at their own anchor index (sparse arrays) and their bit in a pass bitmap (anchor order, one ballot per
 //       wave: no atomics, no memset).
-//   K3: one 512-thread workgroup per image.
+//   K3: one 1024-thread workgroup per image.
 //       * the candidates are the set bits of the bitmap: a block scan of the word popcounts gives every word its first
 //         position (and every survivor its `keep` index later), each thread expands words into 64-bit keys
 //         (~score, anchor);
-//       * bitonic sort of the keys with up to 32 keys per thread in registers: compare-exchanges inside a thread, wave
-//         shuffles for partners inside a wave, LDS only for the few strides that cross waves.  A total order, so the
-//         result does not depend on anything but the values: (score desc, anchor asc), the project's tie rule;
-//       * greedy NMS over the sorted list in SUPER-CHUNKS of 512 boxes (one per thread).  Phase 1: every box against the
-//         boxes kept so far (an LDS list), early exit per wave -- in a busy scene nine boxes in ten die here, against a
-//         list of a few hundred at most.  Phase 2: the survivors (compacted in order) among themselves: their
-//         suppression matrix (row = higher-priority box, one ballot per row and 64-column tile) into LDS by all waves,
-//         then one wave replays the greedy loop on it -- a 64-bit scalar walk per 64 survivors (next alive box is
-//         kept, its diagonal word clears its victims), kept rows OR-ed into the removed words.  Greedy NMS is
-//         order-determined, so the keep set equals the reference's sequential loop (detector.py:365-375); the work is
-//         K x kept + survivors^2 / 2 IoUs instead of the K^2 / 2 of a full suppression matrix.
+//       * the keys are sorted -- up to 4096 of them by a stable LSD radix sort on the score half (k3_radix), more by a bitonic
+//         network in registers / wave shuffles / LDS (k3_sort).  A total order, so the result does not depend on anything but
+//         the values: (score desc, anchor asc), the project's tie rule;
+//       * greedy NMS over the sorted list in rounds of 64, 128, 256, 512, 512 ... boxes.  Phase 1: every box against the boxes
+//         kept so far (an LDS list, from 96 boxes on sorted into centre-x bins so that a box scans only the bins a suppressor's
+//         centre can lie in) -- in a busy scene nine boxes in ten die here.  Phase 2: the survivors (compacted in order) among
+//         themselves: their suppression matrix into LDS by all waves, then one wave replays the greedy order on it, 64
+//         survivors per step.  Greedy NMS is order-determined, so the keep set equals the reference's sequential loop
+//         (detector.py:365-375); the work is K x (a slice of) kept + survivors^2 / 2 IoUs instead of the K^2 / 2 of a full
+//         suppression matrix.  DESIGN.md section 4 (K3) has the details and the cycle counts.
 #include <hip/hip_fp16.h>
 
 #include <cmath>
