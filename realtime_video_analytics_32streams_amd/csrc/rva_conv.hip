@@ -958,6 +958,76 @@ __global__ void __launch_bounds__(256) k_sppf_pool3(const __half *in, int ldi, _
     }
 }
 
+// The same with G groups of 8 channels per block (round 4): consecutive lanes take the G 16-byte pieces of one pixel and then the
+// next pixel, so a wave touches whole 64-byte (G = 4) runs of the NHWC rows instead of one 16-byte piece per 512-byte row, for the
+// loads and for the three stores alike.  1024 threads; the 13-wide row maxima replace the input tile in LDS (they are held in
+// registers across a barrier), so a block needs 3 x HW x G x 16 bytes.  Used when the launch still fills the chip that way.
+template <int G>
+__global__ void __launch_bounds__(1024) k_sppf_pool3g(const __half *in, int ldi, __half *o1, __half *o2, __half *o3, int ldo,
+                                                      int H, int W, int C)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int MAXIT = 4;             // items per thread: HW * G <= 4096
+    const int HW = H * W, n = HW * G, cgb = C / (8 * G);
+    h8 *x = (h8 *)smem;                  // [HW][G]; holds the 13-wide row maxima after the row pass
+    h8 *r5 = x + n, *r9 = r5 + n;
+    const int b = blockIdx.x / cgb, gb = blockIdx.x - b * cgb;
+    const size_t base = (size_t)b * HW;
+    const int c0 = gb * 8 * G;
+    for (int q = threadIdx.x; q < n; q += 1024) x[q] = *reinterpret_cast<const h8 *>(in + (base + q / G) * ldi + c0 + (q % G) * 8);
+    __syncthreads();
+    h8 m13[MAXIT];
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const int q = threadIdx.x + it * 1024;
+        if (q < n) {
+            const int p = q / G, xx = p % W;
+            h8 m = x[q];
+#pragma unroll
+            for (int d = 1; d <= 6; ++d) {
+                if (xx - d >= 0) m = __builtin_elementwise_max(m, x[q - d * G]);
+                if (xx + d < W) m = __builtin_elementwise_max(m, x[q + d * G]);
+                if (d == 2) r5[q] = m;
+                if (d == 4) r9[q] = m;
+            }
+            m13[it] = m;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const int q = threadIdx.x + it * 1024;
+        if (q < n) x[q] = m13[it];
+    }
+    __syncthreads();
+    const int WG = W * G;
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const int q = threadIdx.x + it * 1024;
+        if (q < n) {
+            const int p = q / G, y = p / W;
+            h8 m5 = r5[q], m9 = r9[q], m = x[q];
+#pragma unroll
+            for (int d = 1; d <= 6; ++d) {
+                if (y - d >= 0) {
+                    if (d <= 2) m5 = __builtin_elementwise_max(m5, r5[q - d * WG]);
+                    if (d <= 4) m9 = __builtin_elementwise_max(m9, r9[q - d * WG]);
+                    m = __builtin_elementwise_max(m, x[q - d * WG]);
+                }
+                if (y + d < H) {
+                    if (d <= 2) m5 = __builtin_elementwise_max(m5, r5[q + d * WG]);
+                    if (d <= 4) m9 = __builtin_elementwise_max(m9, r9[q + d * WG]);
+                    m = __builtin_elementwise_max(m, x[q + d * WG]);
+                }
+            }
+            const size_t o = (base + p) * ldo + c0 + (q % G) * 8;
+            *reinterpret_cast<h8 *>(o1 + o) = m5;
+            *reinterpret_cast<h8 *>(o2 + o) = m9;
+            *reinterpret_cast<h8 *>(o3 + o) = m;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // 5x5 stride-1 pad-2 max pool over a channel slice (C % 8 == 0): thread = (pixel, 8 channels)
 __global__ void __launch_bounds__(256) k_maxpool5(const __half *in, int ldi, __half *out, int ldo, int B, int H, int W, int C)
@@ -3476,6 +3546,14 @@ int rva_sppf_pool3_nhwc_f16(rva_ctx *ctx, const void *in, int ldi, void *out1, v
         return rva_fail(ctx, RVA_ERR_ARG, "rva_sppf_pool3_nhwc_f16: bad argument");
     const size_t smem = (size_t)H * W * 16 * 4;
     if (smem > 150 * 1024) return rva_fail(ctx, RVA_ERR_ARG, "rva_sppf_pool3_nhwc_f16: H*W too large for one LDS tile (use rva_maxpool5_nhwc_f16 x3)");
+    // whole 64-byte runs per wave where that still fills the chip (32 frames of YOLOv8s: 256 blocks of 1024 threads)
+    if (C % 32 == 0 && (long)batch * (C / 32) >= 192 && (size_t)H * W * 4 <= 4096 && (size_t)H * W * 4 * 16 * 3 <= 150 * 1024 && !getenv("RVA_SPPF_G1")) {
+        RVA_HIP(ctx, rva_func_smem((const void *)k_sppf_pool3g<4>, 150 * 1024));
+        k_sppf_pool3g<4><<<batch * (C / 32), 1024, (size_t)H * W * 4 * 16 * 3, (hipStream_t)stream_>>>((const __half *)in, ldi, (__half *)out1,
+                                                                                              (__half *)out2, (__half *)out3, ldo, H, W, C);
+        RVA_HIP(ctx, hipGetLastError());
+        return RVA_OK;
+    }
     RVA_HIP(ctx, rva_func_smem((const void *)k_sppf_pool3, 150 * 1024));
     k_sppf_pool3<<<batch * (C / 8), 256, smem, (hipStream_t)stream_>>>((const __half *)in, ldi, (__half *)out1, (__half *)out2,
                                                                        (__half *)out3, ldo, H, W, C);

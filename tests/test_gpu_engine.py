@@ -205,6 +205,16 @@ def test_pool_upsample_head_primitives():
         for i in range(3):
             p = F.max_pool2d(p, 5, 1, 2)
             assert torch.equal(xs[..., 40 + 24 * i:64 + 24 * i].float(), p.permute(0, 2, 3, 1)), (hh, ww, i)
+    # the bench shape (32 frames x 256 channels at 20 x 20: the four-groups-per-block kernel) and an odd size on the same path
+    for (bb, hh, ww, cc) in ((32, 20, 20, 256), (24, 13, 17, 256), (6, 20, 20, 1024)):
+        xs = torch.randn((bb, hh, ww, 32 + 4 * cc)).half().cuda()                    # [skip 32 | x | y1 | y2 | y3]
+        ld = 32 + 4 * cc
+        ctx.check(L.rva_sppf_pool3_nhwc_f16(ctx.handle, C.c_void_p(xs.data_ptr() + 2 * 32), ld, C.c_void_p(xs.data_ptr() + 2 * (32 + cc)),
+                                            C.c_void_p(xs.data_ptr() + 2 * (32 + 2 * cc)), C.c_void_p(xs.data_ptr() + 2 * (32 + 3 * cc)), ld, bb, hh, ww, cc, s))
+        p = xs[..., 32:32 + cc].permute(0, 3, 1, 2).float()
+        for i in range(3):
+            p = F.max_pool2d(p, 5, 1, 2)
+            assert torch.equal(xs[..., 32 + cc * (i + 1):32 + cc * (i + 2)].float(), p.permute(0, 2, 3, 1)), (bb, hh, ww, cc, i)
     up = torch.zeros((2, 40, 40, 32), dtype=torch.float16, device="cuda")
     ctx.check(L.rva_upsample2x_nhwc_f16(ctx.handle, C.c_void_p(out.data_ptr()), 32, C.c_void_p(up.data_ptr()), 32, 2, 20, 20, 32, s))
     assert torch.equal(up, out.repeat_interleave(2, 1).repeat_interleave(2, 2))
