@@ -127,6 +127,32 @@ def test_postprocess_busy_images_across_sort_sizes_and_nms_rounds():
     assert ops.post_status() == 0
 
 
+@pytest.mark.parametrize("A,n_boxes", [(4096, 3000), (8400, 6000)])
+def test_postprocess_more_kept_boxes_than_the_lds_list_holds(A, n_boxes):
+    """Thousands of boxes that barely overlap: the kept list outgrows its LDS copy (1024 boxes; 512 in the 16384-key layout that
+    6000 candidates select) and phase 1 reads the rest back from the output rows -- with the LDS part sorted into centre bins.  A
+    jittered grid of small boxes with a sprinkling of duplicates (suppressed by a box that may sit in either part)."""
+    rng = np.random.default_rng(A)
+    p = np.zeros((A, 84), np.float32)
+    idx = rng.permutation(A)[:n_boxes]
+    side = int(np.ceil(np.sqrt(n_boxes * 0.9)))
+    cell_w, cell_h = 620.0 / side, 340.0 / side
+    g = rng.permutation(side * side)[:n_boxes] if side * side >= n_boxes else rng.integers(0, side * side, n_boxes)
+    p[idx, 0] = 10 + (g % side + 0.5) * cell_w + rng.uniform(-0.1, 0.1, n_boxes) * cell_w
+    p[idx, 1] = 150 + (g // side + 0.5) * cell_h + rng.uniform(-0.1, 0.1, n_boxes) * cell_h
+    p[idx, 2] = cell_w * rng.uniform(0.7, 1.0, n_boxes); p[idx, 3] = cell_h * rng.uniform(0.7, 1.0, n_boxes)
+    p[idx, 4] = 1.0
+    p[idx, 5] = rng.uniform(0.3, 1.0, n_boxes).astype(np.float32)
+    raw = np.ascontiguousarray(p.T)
+    ops.post_filter_stats()
+    got = _post_one(raw, 0.25, 0.5, None, (1920, 1080))
+    want = orc.postprocess(raw, 0.25, 0.5, None, (1920, 1080))
+    assert ops.post_filter_stats() == 1 and ops.post_status() == 0
+    assert want["n"] > 1024 + 512 and want["n"] < n_boxes                     # far past the LDS list; some were suppressed
+    assert got["n"] == want["n"] and np.array_equal(got["anchor"], want["anchor"])
+    assert np.array_equal(got["boxes"], want["boxes"]) and np.array_equal(got["conf"], want["conf"])
+
+
 def test_postprocess_suppression_decisions_at_the_threshold_boundary():
     """K3 decides `iou > thr` without dividing (an exact comparison in float64 against the point where the rounded quotient
     leaves thr).  Pairs of boxes whose float32 IoU lands within a few ulps of the threshold, on both sides of it and on it:
