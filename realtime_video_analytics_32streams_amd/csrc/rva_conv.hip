@@ -1774,6 +1774,215 @@ hipError_t launch_run(RunArgs &a, hipStream_t s)
 }
 
 // ---------------------------------------------------------------------------------------------------
+// 3x3 STRIDE-2 convolution in the "long run" form (round 4).
+//
+// The five downsampling convolutions of YOLOv8 ran on the gather kernels (k_conv_gbig): every tap of a K-step fetches its own
+// BM rows, nine fetches of the input per output tile -- 0.57-0.70 PFLOP/s against the 0.9 of k_conv3_run on the stride-1 layers.
+// Here a tile is BM consecutive positions of the PADDED OUTPUT raster (row pitch Wo + 1: one pad position after every output
+// row), and a (32-channel chunk, dy) step stages the input row 2 oy + dy - 1 of every position ONCE, split by column parity:
+//   plane E, row t      = input pixel (2 oy + dy - 1, 2 ox)      of position P0 + t        -> the dx = 1 tap of position P0 + t
+//   plane O, row t      = input pixel (2 oy + dy - 1, 2 ox + 1)  of position P0 - 1 + t    -> the dx = 0 tap of position P0 + t
+//                                                                                           and the dx = 2 tap of P0 + t - 1
+// so the three horizontal taps of a fragment are three FIXED row offsets into what the step staged (LDS-DMA takes a source address
+// per lane: the stride-2 walk over the input costs nothing), 2 BM + 1 rows per three taps instead of 3 BM.  Padding without a
+// select in the MFMA phase, as in k_conv3_run<PADO>: the lanes of a piece whose row is a pad position (the O row before ox = 0 is
+// the pad position that ends the previous output row: the left padding) or lies above the image (oy = 0 at dy = 0) are masked out
+// of the DMA, and their 16 bytes, zeroed once, are never written -- which is why the steps of each dy have a buffer of their own
+// (three activation buffers; weights double-buffered as in k_conv3_run).  Even H and W (no bottom / right padding arises),
+// Cin % 32 == 0.  LDS: 3 x (2 BM + 16) x 64 B + 2 x 3 BN x 64 B: 147 KB for 256 x 128, 75 KB for 128 x 64.
+template <int BM, int BN, int WGM, int WGN>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BM <= 128 && BN <= 64 ? 4 : 2))) k_conv3_s2run(RunArgs a)
+{
+    static_assert(WGM * WGN == 8, "eight waves");
+    constexpr int TM = BM / WGM, TN = BN / WGN, FM = TM / 16, FN = TN / 16;
+    constexpr int WPIECES = 3 * BN / 16, NPW = (WPIECES + 7) / 8;
+    constexpr int BMO = (BM + 1 + 15) / 16 * 16;          // rows of plane O (BM + 1 used), plane E follows
+    constexpr int AP = (BMO + BM) / 16, MAXA = (AP + 7) / 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv % WGM, wn = wv / WGM;
+    const int n_tile = (blockIdx.x >> 3) % a.n_tiles, m_tile = ((blockIdx.x >> 3) / a.n_tiles) * 8 + (blockIdx.x & 7);   // XCD-aware, see k_conv3_big
+    if (m_tile >= a.m_tiles) return;
+    const int P0 = m_tile * BM, n0 = n_tile * BN;
+    const int Ho = a.H >> 1, Wo = a.W >> 1, Wp = Wo + 1, HWp = Ho * Wp;
+    const int cpt = a.Cin >> 5, nsteps = 3 * cpt, wrow = 9 * a.Cin;
+    __half *act0 = (__half *)smem;                        // [3 dy][AP][16][32]
+    __half *wt0 = act0 + (size_t)3 * AP * 512;            // [2][WPIECES][16][32]
+    const unsigned lds_act = lds_addr(act0), lds_w = lds_addr(wt0);
+    const int lrow = lane >> 2, lp = lane & 3;
+    const float inv_wp = 1.0f / (float)Wp, inv_hwp = 1.0f / (float)HWp;
+    const int batch = a.M / (Ho * Wo);
+    // position of the padded output raster -> (image, oy, ox); ox == Wo is the pad position
+    unsigned aoff[MAXA], woff[NPW];
+    unsigned long long am1[MAXA], am0[MAXA];              // lanes whose row is a real input pixel at dy >= 1 / at dy = 0
+#pragma unroll
+    for (int k = 0; k < MAXA; ++k) {
+        const int r = (wv + 8 * k) * 16 + lrow;           // row of the step's buffer
+        const bool odd = r < BMO;
+        const int pos = odd ? P0 - 1 + r : P0 + (r - BMO);
+        bool ok = (odd ? r <= BM : r < BMO + BM) && pos >= 0;
+        int b = 0, oy = 0, ox = 0;
+        if (ok) {
+            b = div_s(pos, HWp, inv_hwp);
+            const int rem = pos - b * HWp;
+            oy = div_s(rem, Wp, inv_wp); ox = rem - oy * Wp;
+            ok = ox < Wo && b < batch;
+        }
+        am1[k] = __builtin_amdgcn_ballot_w64(ok);
+        am0[k] = __builtin_amdgcn_ballot_w64(ok && oy >= 1);
+        const int ipix = ok ? (b * a.H + 2 * oy) * a.W + 2 * ox + (odd ? 1 : 0) : 0;       // the dy = 1 row; dy = 0 / 2 shift the base
+        aoff[k] = (unsigned)ipix * (unsigned)(a.ldi * 2) + (unsigned)(((lp - 2 * (r >> 2)) & 3) * 16);
+    }
+    int *rowmap = (int *)(smem + a.map_off);              // output pixel index of every row of the tile, -1 = skip
+    for (int r = tid; r < BM; r += 512) {
+        const int pos = P0 + r;
+        const int b = div_s(pos, HWp, inv_hwp), rem = pos - b * HWp, oy = div_s(rem, Wp, inv_wp), ox = rem - oy * Wp;
+        rowmap[r] = (ox < Wo && b < batch) ? (b * Ho + oy) * Wo + ox : -1;
+    }
+    for (int i = tid; i < 3 * AP * 64; i += 512) reinterpret_cast<uint4 *>(smem)[i] = uint4{0u, 0u, 0u, 0u};     // the masked lanes' bytes stay zero
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NPW; ++k) {
+        const int rw = (wv + 8 * k) * 16 + lrow;
+        const int dx = rw / BN, co = min(n0 + rw - dx * BN, a.CoutPad - 1);
+        woff[k] = (unsigned)(co * wrow + min(dx, 2) * a.Cin) * 2u + (unsigned)(((lp - 2 * (rw >> 2)) & 3) * 16);
+    }
+    f4 acc[FN][FM];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+    float4 bvs[FN];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+        bvs[i] = *reinterpret_cast<const float4 *>(a.bias + min(n0 + wn * TN + 16 * i + (lane >> 4) * 4, a.CoutPad - 4));
+    const long long rowb = (long long)a.W * a.ldi * 2;    // bytes of an input row
+    // step (cc, dy): activations into buffer dy, weights into buffer (step & 1)
+    auto issue = [&](int step, int cc, int dy) {
+        const char *wb_ = (const char *)a.w + (size_t)(dy * 3 * a.Cin + cc * 32) * 2;
+        const unsigned lw_ = lds_w + (unsigned)(step & 1) * (unsigned)(WPIECES * 1024);
+#pragma unroll
+        for (int k = 0; k < NPW; ++k)
+            if (wv + 8 * k < WPIECES) lds_dma16(woff[k], wb_, lw_ + (unsigned)(wv + 8 * k) * 1024u);
+        const char *ab_ = (const char *)a.in + (long long)cc * 64 + (long long)(dy - 1) * rowb;
+        const unsigned la_ = lds_act + (unsigned)dy * (unsigned)(AP * 1024);
+#pragma unroll
+        for (int k = 0; k < MAXA; ++k)
+            if (wv + 8 * k < AP) lds_dma16_masked(aoff[k], ab_, la_ + (unsigned)(wv + 8 * k) * 1024u, dy == 0 ? am0[k] : am1[k]);
+    };
+    issue(0, 0, 0);
+    const int wlane = swz32(wn * TN + (lane & 15), lane >> 4);      // this lane's weight row of fragment 0, tap 0
+    const int t0 = wm * TM + (lane & 15), ch = lane >> 4;
+    const int abase[3] = {swz32(t0, ch), swz32(BMO + t0, ch), swz32(t0 + 1, ch)};      // dx = 0: O[t], dx = 1: E[t], dx = 2: O[t + 1]
+    int cc = 0, dy = 0;
+    for (int s = 0; s < nsteps; ++s) {
+        wait_vm<0>();                                     // what this wave issued a step ago has landed ...
+        __builtin_amdgcn_s_barrier();                     // ... and everybody's has; nobody still reads what the next burst overwrites
+        int ncc = cc, ndy = dy + 1;
+        if (ndy == 3) { ndy = 0; ++ncc; }
+        ncc = __builtin_amdgcn_readfirstlane(ncc);
+        ndy = __builtin_amdgcn_readfirstlane(ndy);
+        const bool early = wv < 4;                        // waves w and w + 4 share a SIMD: see k_conv3_run
+        if (early && s + 1 < nsteps) issue(s + 1, ncc, ndy);
+        const __half *ab = act0 + (size_t)dy * AP * 512;
+        const __half *wb = wt0 + (size_t)(s & 1) * WPIECES * 512;
+        h8 bfx[2][FM], afx[2][FN];
+#define S2_LOAD(S, DX)                                                                                           \
+        do {                                                                                                     \
+            _Pragma("unroll") for (int j = 0; j < FM; ++j)                                                       \
+                bfx[S][j] = *reinterpret_cast<const h8 *>(ab + abase[DX] + j * (16 * 32));                       \
+            _Pragma("unroll") for (int i = 0; i < FN; ++i)                                                       \
+                afx[S][i] = *reinterpret_cast<const h8 *>(wb + wlane + ((DX) * BN + i * 16) * 32);               \
+        } while (0)
+#define S2_MFMA(S)                                                                                               \
+        do {                                                                                                     \
+            _Pragma("unroll") for (int i = 0; i < FN; ++i)                                                       \
+                _Pragma("unroll") for (int j = 0; j < FM; ++j)                                                   \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afx[S][i], bfx[S][j], acc[i][j], 0, 0, 0); \
+        } while (0)
+        S2_LOAD(0, 0);
+        S2_LOAD(1, 1);
+        S2_MFMA(0);
+        if (!early && s + 1 < nsteps) issue(s + 1, ncc, ndy);
+        S2_LOAD(0, 2);
+        S2_MFMA(1);
+        S2_MFMA(0);
+#undef S2_LOAD
+#undef S2_MFMA
+        cc = ncc; dy = ndy;
+    }
+    __syncthreads();     // all waves done with the buffers: reuse them as the output staging tile
+
+    constexpr int SROW = BN + 8;
+    __half *stage = (__half *)smem;                       // [BM][SROW]
+#pragma unroll
+    for (int i = 0; i < FN; ++i) {
+        const int co = wn * TN + 16 * i + (lane >> 4) * 4;
+        const float4 bv = bvs[i];
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+            float v0 = acc[i][j][0] + bv.x, v1 = acc[i][j][1] + bv.y, v2 = acc[i][j][2] + bv.z, v3 = acc[i][j][3] + bv.w;
+            if (a.act) { v0 = silu_f(v0); v1 = silu_f(v1); v2 = silu_f(v2); v3 = silu_f(v3); }
+            const int px = wm * TM + 16 * j + (lane & 15);
+            __half2 lo = __floats2half2_rn(v0, v1), hi = __floats2half2_rn(v2, v3);
+            uint2 pk;
+            pk.x = *reinterpret_cast<uint32_t *>(&lo);
+            pk.y = *reinterpret_cast<uint32_t *>(&hi);
+            *reinterpret_cast<uint2 *>(stage + (size_t)px * SROW + co) = pk;
+        }
+    }
+    __syncthreads();
+    constexpr int CPR = BN / 8;
+#pragma unroll 4
+    for (int q = tid; q < BM * CPR; q += 512) {
+        const int row = q / CPR, pc = q - row * CPR;
+        const int co = n0 + pc * 8;
+        const int m = rowmap[row];
+        if (m >= 0 && co < a.Cout) {
+            uint4 v = *reinterpret_cast<const uint4 *>(stage + (size_t)row * SROW + pc * 8);
+            if (a.res) {
+                const uint4 r = *reinterpret_cast<const uint4 *>(a.res + (size_t)m * a.ldr + co);
+                __half2 *vh = reinterpret_cast<__half2 *>(&v);
+                const __half2 *rh = reinterpret_cast<const __half2 *>(&r);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float2 x = __half22float2(vh[u]), y = __half22float2(rh[u]);
+                    vh[u] = __floats2half2_rn(x.x + y.x, x.y + y.y);
+                }
+            }
+            *reinterpret_cast<uint4 *>(a.out + (size_t)m * a.ldo + co) = v;
+        }
+    }
+}
+
+// a.H / a.W: INPUT size (even), a.M: output pixels
+template <int BM, int BN, int WGM, int WGN>
+hipError_t launch_s2run(RunArgs &a, hipStream_t s)
+{
+    constexpr int BMO = (BM + 1 + 15) / 16 * 16, AP = (BMO + BM) / 16;
+    if (a.Cin % 32 || a.CoutPad % 4 || (a.H & 1) || (a.W & 1)) return hipErrorInvalidValue;
+    const int Ho = a.H / 2, Wo = a.W / 2;
+    if (Ho <= 0 || Wo <= 0 || a.M % (Ho * Wo)) return hipErrorInvalidValue;
+    const long batch = a.M / (Ho * Wo);
+    const long mp = batch * Ho * (Wo + 1);                // positions of the padded output raster (div_s: below 2^24)
+    if (mp >= (1l << 24)) return hipErrorInvalidValue;
+    // LDS-DMA addresses: a 64-bit scalar base + a 32-bit per-lane byte offset
+    if ((size_t)batch * a.H * a.W * a.ldi * 2 >= (1ull << 32) || (size_t)a.CoutPad * 9 * a.Cin * 2 >= (1ull << 32)) return hipErrorInvalidValue;
+    const size_t ring = (size_t)(3 * AP + 2 * (3 * BN / 16)) * 1024;
+    const size_t st = (size_t)BM * (BN + 8) * 2;
+    size_t smem = ring > st ? ring : st;
+    a.map_off = (int)smem;
+    smem += (size_t)BM * 4;
+    if (smem > 160 * 1024) return hipErrorInvalidValue;
+    if (hipError_t e = rva_func_smem((const void *)k_conv3_s2run<BM, BN, WGM, WGN>, 160 * 1024); e != hipSuccess) return e;
+    a.n_tiles = rva_ceil_div(a.Cout, BN);
+    a.m_tiles = (int)((mp + BM - 1) / BM);
+    k_conv3_s2run<BM, BN, WGM, WGN><<<rva_ceil_div(a.m_tiles, 8) * 8 * a.n_tiles, 512, smem, s>>>(a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
 // 3x3 stride-1 convolution, "whole chunk per barrier" LDS-DMA variant (round 4) for layers with FEW pixels.
 //
 // Where k_conv3_run pays off it is because a 256 x 128 tile has ~1.5 k cycles of MFMA work per (chunk, dy) step to set
@@ -3032,9 +3241,9 @@ __global__ void __launch_bounds__(1024) k_stem2(Stem2Args a)
 
 }  // namespace
 
-#define RVA_CONV_VARIANTS 85
+#define RVA_CONV_VARIANTS 89
 #ifdef RVA_EXPERIMENTS
-#define RVA_CONV_VARIANTS_MAX 99      // 90..: timing-only experiment kernels of a private build (tools/exp_build.py), never in librva.so
+#define RVA_CONV_VARIANTS_MAX 99      // 96..: timing-only experiment kernels of a private build (tools/exp_build.py), never in librva.so
 #else
 #define RVA_CONV_VARIANTS_MAX RVA_CONV_VARIANTS
 #endif
@@ -3123,6 +3332,24 @@ int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *wei
             if (rc == RVA_OK) return rc;
         }
     }
+    if (variant >= 86 && variant <= 89) {
+        // stride-2 "long run" kernels on the padded output raster: see k_conv3_s2run
+        hipError_t ev = hipErrorInvalidValue;
+        if (ksize == 3 && stride == 2) {
+            RunArgs g{};
+            g.in = a.in; g.ldi = ldi; g.w = a.w; g.bias = bias; g.out = a.out; g.ldo = ldo; g.res = a.res; g.ldr = ldr;
+            g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.CoutPad = rva_ceil_div(Cout, 64) * 64; g.act = act; g.M = a.M;
+            switch (variant) {
+            case 86: ev = launch_s2run<256, 128, 4, 2>(g, s); break;     // 147 KB
+            case 87: ev = launch_s2run<256, 64, 4, 2>(g, s); break;      // 123 KB
+            case 88: ev = launch_s2run<128, 128, 2, 4>(g, s); break;     // 99 KB
+            default: ev = launch_s2run<128, 64, 2, 4>(g, s); break;      // 75 KB: two blocks per CU
+            }
+        }
+        if (ev == hipSuccess) return RVA_OK;
+        (void)hipGetLastError();
+        return rva_fail(ctx, ev == hipErrorInvalidValue ? RVA_ERR_ARG : RVA_ERR_HIP, "conv variant %d not applicable here", variant);
+    }
     if (variant >= 80 && variant <= 85) {
         // "long run" kernels on the padded raster (no padding selects in the MFMA phase): see k_conv3_run<..., PADO>
         hipError_t ev = hipErrorInvalidValue;
@@ -3144,15 +3371,15 @@ int rva_conv2d_nhwc_f16_v(rva_ctx *ctx, const void *in, int ldi, const void *wei
         return rva_fail(ctx, ev == hipErrorInvalidValue ? RVA_ERR_ARG : RVA_ERR_HIP, "conv variant %d not applicable here", variant);
     }
 #ifdef RVA_EXPERIMENTS
-    if (variant >= 90) {
+    if (variant >= 96) {
         hipError_t ev = hipErrorInvalidValue;
         if (ksize == 3 && stride == 1) {
             RunArgs g{};
             g.in = a.in; g.ldi = ldi; g.w = a.w; g.bias = bias; g.out = a.out; g.ldo = ldo; g.res = a.res; g.ldr = ldr;
             g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.CoutPad = rva_ceil_div(Cout, 64) * 64; g.act = act; g.M = a.M;
             const char *nosel = getenv("RVA_NOSEL");      // the select-free kernels give wrong border pixels: opt-in per process
-            if (variant == 90) { if (nosel && nosel[0] == '1') ev = launch_run<256, 128, 4, 2, true>(g, s); }       // run<256,128> without the padding selects
-            else if (variant == 91) { if (nosel && nosel[0] == '1') ev = launch_run<256, 64, 4, 2, true>(g, s); }   // run<256,64> without the padding selects
+            if (variant == 96) { if (nosel && nosel[0] == '1') ev = launch_run<256, 128, 4, 2, true>(g, s); }       // run<256,128> without the padding selects
+            else if (variant == 97) { if (nosel && nosel[0] == '1') ev = launch_run<256, 64, 4, 2, true>(g, s); }   // run<256,64> without the padding selects
         }
         if (ev == hipSuccess) return RVA_OK;
         (void)hipGetLastError();

@@ -89,7 +89,10 @@ def test_conv_primitive_matches_fp32_reference(shape):
                                    # 32-channel-step LDS-DMA gather: the Cin = 32 / 96 layers
                                    (2, 21, 18, 32, 64, 3, 2), (2, 16, 16, 96, 64, 1, 1), (1, 160, 160, 32, 64, 3, 2),
                                    # YOLOv8m widths at batch 4 (BASELINE configs[3] per GPU): the whole-chunk-per-barrier kernels, 96-channel tiles
-                                   (4, 40, 40, 192, 192, 3, 1), (4, 20, 20, 288, 288, 3, 1), (3, 23, 37, 96, 96, 3, 1)])
+                                   (4, 40, 40, 192, 192, 3, 1), (4, 20, 20, 288, 288, 3, 1), (3, 23, 37, 96, 96, 3, 1),
+                                   # stride-2 long-run kernels (even sizes): tiles that straddle rows and images, Cout below / across the
+                                   # channel tile, a tensor smaller than one tile, the widest layer of the plan
+                                   (3, 40, 40, 128, 192, 3, 2), (5, 24, 36, 96, 96, 3, 2), (1, 6, 4, 64, 64, 3, 2), (2, 160, 160, 64, 128, 3, 2)])
 def test_every_conv_variant_agrees(shape):
     """All kernel variants the autotuner may pick (gather / resident / row-reuse, every tile) give the same layer."""
     B, H, W, Cin, Cout, k, stride = shape
@@ -122,6 +125,8 @@ def test_every_conv_variant_agrees(shape):
             assert any(21 <= v <= 32 for v in ran), ran      # the large-tile LDS-DMA kernel took part
     if Cin % 32 == 0:
         assert any(v >= 40 for v in ran), ran          # the 32-channel-step LDS-DMA gather kernel took part
+    if k == 3 and stride == 2 and Cin % 32 == 0 and H % 2 == 0 and W % 2 == 0:
+        assert all(v in ran for v in (86, 87, 88, 89)), ran    # the stride-2 long-run kernels took part
     if Cin % 64 == 0 and (k == 3 or stride == 1):
         assert all(v in ran for v in range(74, 80)), ran   # the gather kernels with several K-steps per barrier took part
         if k == 3 and stride == 1 and W <= 160:

@@ -1,5 +1,5 @@
-"""Private build of librva with -DRVA_EXPERIMENTS (timing-only experiment kernels, variants 90..) into tools/_dbg/librva_exp.so
-(git-ignored, travels with gpurun).  Use:  RVA_LIB_PATH=tools/_dbg/librva_exp.so python tools/sweep_run.py ... 56 90"""
+"""Private build of librva with -DRVA_EXPERIMENTS (timing-only experiment kernels, variants 96.. -- 90 / 91 when round 4's A/Bs were recorded, before the stride-2 kernels took 86-93) into tools/_dbg/librva_exp.so
+(git-ignored, travels with gpurun).  Use:  RVA_LIB_PATH=tools/_dbg/librva_exp.so python tools/sweep_run.py ... 56 96"""
 import subprocess, sys
 from pathlib import Path
 sys.path.insert(0, ".")
