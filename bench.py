@@ -68,6 +68,8 @@ def parse():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the measurements taken after the timed region (cold K1 launch, device copy bandwidth, "
                          "post-process / tracker load sweep)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the two child runs (4 x YOLOv8m, 4 x YOLOv8n) that the default headline run appends to its record")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames in the CPU-baseline sample (0 = auto)")
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark = True")
     ap.add_argument("--no-graph", action="store_true",
@@ -473,6 +475,8 @@ def main():
                     out["max_latency_ms"], out["latency_samples"] = out["long_run"]["max_ms"], out["long_run"]["ticks"]
                     out["latency_source"] = "long_run (saturated ticks after the timed region, same runner)"
                 out["paced_30fps"] = paced_leg(args, det, sources[:S], streams, tcfg, fps)
+                if args.model == "s" and S == 32 and not args.no_other_configs:
+                    out["other_configs"] = other_configs_leg(args)
         except Exception as exc:  # noqa: BLE001  -- the measurements after the timed region never cost the headline line
             import traceback
             traceback.print_exc()
@@ -484,6 +488,32 @@ def main():
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+
+
+def other_configs_leg(args):
+    """BASELINE configs[1] and one GPU's share of configs[3] in the same record: 4 x YOLOv8n and 4 x YOLOv8m (the 4 streams per GPU
+    of 32 x YOLOv8m over 8 GPUs), each measured by a CHILD process running this file (this process has finished its own legs and
+    leaves the GPU idle; a child, never an exec).  A failure or timeout of a child is recorded, it never costs the headline."""
+    import subprocess
+    res = {"what": "python bench.py --model <m> --streams 4 --steps <k> --warmup <w> --no-cpu-baseline --no-extras, one child process each, "
+                   "after every other leg of this run"}
+    for key, model, steps, warm in (("configs3_share_4x_yolov8m", "m", 200, 40), ("configs1_4x_yolov8n", "n", 300, 60)):
+        cmd = [sys.executable, os.path.abspath(__file__), "--model", model, "--streams", "4", "--steps", str(steps), "--warmup", str(warm),
+               "--no-cpu-baseline", "--no-extras", "--width", str(args.width), "--height", str(args.height)]
+        try:
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+            line = next((ln for ln in reversed(p.stdout.strip().splitlines()) if ln.startswith("{")), None)
+            if p.returncode != 0 or line is None:
+                res[key] = {"error": f"exit {p.returncode}: {(p.stderr or '').strip().splitlines()[-1][:200] if p.stderr else ''}"}
+                continue
+            d = json.loads(line)
+            res[key] = {"frames_per_s": d["value"], "ms_per_tick": d["ms_per_step"], "p99_latency_ms": d.get("p99_latency_ms"),
+                        "steps": d["steps"], "ticks_in_flight": d.get("ticks_in_flight"), "detector": d["config"].get("detector"),
+                        "network_launch": (d.get("network_launch") or {}).get("mode"),
+                        "detector_frac_of_mfma_peak_in_pipeline": d.get("detector_frac_of_mfma_peak_in_pipeline")}
+        except Exception as exc:  # noqa: BLE001
+            res[key] = {"error": f"{type(exc).__name__}: {exc}"}
+    return res
 
 
 def _percentiles(lat_s):
