@@ -491,15 +491,19 @@ def main():
 
 
 def other_configs_leg(args):
-    """BASELINE configs[1] and one GPU's share of configs[3] in the same record: 4 x YOLOv8n and 4 x YOLOv8m (the 4 streams per GPU
-    of 32 x YOLOv8m over 8 GPUs), each measured by a CHILD process running this file (this process has finished its own legs and
+    """BASELINE configs[1], one GPU's share of configs[3] and configs[4] in the same record: 4 x YOLOv8n, 4 x YOLOv8m (the 4 streams per GPU
+    of 32 x YOLOv8m over 8 GPUs) and the 4K CNN-LSTM clip workload, each measured by a CHILD process running this file (this process has finished its own legs and
     leaves the GPU idle; a child, never an exec).  A failure or timeout of a child is recorded, it never costs the headline."""
     import subprocess
-    res = {"what": "python bench.py --model <m> --streams 4 --steps <k> --warmup <w> --no-cpu-baseline --no-extras, one child process each, "
-                   "after every other leg of this run"}
-    for key, model, steps, warm in (("configs3_share_4x_yolov8m", "m", 200, 40), ("configs1_4x_yolov8n", "n", 300, 60)):
-        cmd = [sys.executable, os.path.abspath(__file__), "--model", model, "--streams", "4", "--steps", str(steps), "--warmup", str(warm),
-               "--no-cpu-baseline", "--no-extras", "--width", str(args.width), "--height", str(args.height)]
+    res = {"what": "python bench.py --model <m> --streams 4 --steps <k> --warmup <w> --no-cpu-baseline --no-extras (and --workload temporal), "
+                   "one child process each, after every other leg of this run"}
+    for key, model, steps, warm in (("configs3_share_4x_yolov8m", "m", 200, 40), ("configs1_4x_yolov8n", "n", 300, 60),
+                                    ("configs4_temporal_8x4k_cnn_lstm", None, 0, 0)):
+        if model is None:      # BASELINE configs[4]: `--workload temporal` with its own defaults (8 x 4K streams, CNN-LSTM clips)
+            cmd = [sys.executable, os.path.abspath(__file__), "--workload", "temporal", "--no-cpu-baseline", "--no-extras"]
+        else:
+            cmd = [sys.executable, os.path.abspath(__file__), "--model", model, "--streams", "4", "--steps", str(steps), "--warmup", str(warm),
+                   "--no-cpu-baseline", "--no-extras", "--width", str(args.width), "--height", str(args.height)]
         try:
             p = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
             line = next((ln for ln in reversed(p.stdout.strip().splitlines()) if ln.startswith("{")), None)
@@ -511,6 +515,8 @@ def other_configs_leg(args):
                         "steps": d["steps"], "ticks_in_flight": d.get("ticks_in_flight"), "detector": d["config"].get("detector"),
                         "network_launch": (d.get("network_launch") or {}).get("mode"),
                         "detector_frac_of_mfma_peak_in_pipeline": d.get("detector_frac_of_mfma_peak_in_pipeline")}
+            if model is None:
+                res[key]["clips_per_s"] = d.get("clips_per_s")
         except Exception as exc:  # noqa: BLE001
             res[key] = {"error": f"{type(exc).__name__}: {exc}"}
     return res
