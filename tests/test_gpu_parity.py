@@ -153,6 +153,26 @@ def test_postprocess_more_kept_boxes_than_the_lds_list_holds(A, n_boxes):
     assert np.array_equal(got["boxes"], want["boxes"]) and np.array_equal(got["conf"], want["conf"])
 
 
+def test_postprocess_detection_cap_keeps_the_first_rows_and_raises_the_flag():
+    """max_det below the number of boxes an image keeps (the reference has no cap): the rows written are the first max_det rows of
+    the uncapped result, the count is max_det and bit 0 of rva_post_status() is set -- with the kept list short (unsorted scan) and
+    long (centre bins: the cap sits inside the sorted list)."""
+    heads = synth.make_head_batch([700, 701, 702, 703], layout="CA", n_obj=220)
+    t = torch.from_numpy(heads).to(DEV)
+    lb = [N.letterbox(1920, 1080, 640, 640)]
+    full = ops.postprocess(t, 0.25, 0.45, None, lb).to_host()
+    assert ops.post_status() == 0 and min(r["n"] for r in full) > 150
+    for cap in (16, 128):
+        res = ops.postprocess(t, 0.25, 0.45, None, lb, max_det=cap).to_host()
+        assert ops.post_status() & 1
+        for got, ref in zip(res, full):
+            assert got["n"] == cap
+            assert np.array_equal(got["anchor"], ref["anchor"][:cap]) and np.array_equal(got["boxes"], ref["boxes"][:cap])
+            assert np.array_equal(got["conf"], ref["conf"][:cap]) and np.array_equal(got["cls"], ref["cls"][:cap])
+    want = orc.postprocess(heads[0], 0.25, 0.45, None, (1920, 1080))
+    assert np.array_equal(full[0]["anchor"], want["anchor"])
+
+
 def test_postprocess_suppression_decisions_at_the_threshold_boundary():
     """K3 decides `iou > thr` without dividing (an exact comparison in float64 against the point where the rounded quotient
     leaves thr).  Pairs of boxes whose float32 IoU lands within a few ulps of the threshold, on both sides of it and on it:
