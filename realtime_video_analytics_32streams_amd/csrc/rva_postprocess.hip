@@ -289,8 +289,8 @@ __device__ __forceinline__ void k3_sort(unsigned long long *keys, int tid)
     __syncthreads();
 }
 
-// Stable LSD radix sort of the K valid keys by their high 32 bits (the score part), 8 bits per pass, src -> dst -> src ...: four
-// passes end in `a`.  The keys were written in anchor order and equal scores keep it, so the result is the bitonic sort's total
+// Stable LSD radix sort of the K valid keys by their high 32 bits (the score part), 8 bits per pass over the bits in which the keys
+// differ, src -> dst -> src ... (an odd number of passes is copied back into `a`).  The keys were written in anchor order and equal scores keep it, so the result is the bitonic sort's total
 // order (score descending, anchor ascending) at a third of its vector instructions.  Wave w owns elements [w 64 E, (w + 1) 64 E),
 // slot e of lane l is element w 64 E + 64 e + l: the stable order inside a wave is (slot, lane).  Per pass: a wave counts its
 // digits slot by slot (lanes with the same digit find one another with eight ballots; the rank of an element among them is a
@@ -302,8 +302,26 @@ __device__ __forceinline__ void k3_radix(unsigned long long *a, unsigned long lo
     const int lane = tid & 63, wave = tid >> 6;
     unsigned long long *src = a, *dst = b2;
     int *wh = hist + wave * 256;
-    for (int pass = 0; pass < 4; ++pass) {
-        const int sh = 32 + 8 * pass;
+    // Only the bits in which the score keys DIFFER need sorting: the scores of an fp16 head carry 11 significant bits (the low 13
+    // bits of every float32 key are zero) and sit within a factor of four of one another -- 12-13 varying bits, two passes
+    // instead of four.  OR and AND of all keys: a wave reduction, then one LDS atomic per wave.
+    unsigned vor = 0u, vand = ~0u;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int idx = wave * 64 * E + e * 64 + lane;
+        if (idx < K) { const unsigned h = (unsigned)(a[idx] >> 32); vor |= h; vand &= h; }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { vor |= __shfl_xor(vor, o); vand &= __shfl_xor(vand, o); }
+    if (tid == 0) { wtot[8] = 0; wtot[9] = -1; }
+    __syncthreads();
+    if (lane == 0) { atomicOr(reinterpret_cast<unsigned *>(wtot) + 8, vor); atomicAnd(reinterpret_cast<unsigned *>(wtot) + 9, vand); }
+    __syncthreads();
+    const unsigned varying = reinterpret_cast<unsigned *>(wtot)[8] ^ reinterpret_cast<unsigned *>(wtot)[9];
+    if (varying == 0u) return;                            // all scores equal: anchor order is the answer already (uniform)
+    const int lowbit = __builtin_ctz(varying), npass = (32 - __builtin_clz(varying) - lowbit + 7) >> 3;
+    for (int pass = 0; pass < npass; ++pass) {
+        const int sh = 32 + lowbit + 8 * pass;
         for (int i = tid; i < K3_WAVES * 256; i += K3_THREADS) hist[i] = 0;
         __syncthreads();
         unsigned long long v[E];
@@ -357,6 +375,10 @@ __device__ __forceinline__ void k3_radix(unsigned long long *a, unsigned long lo
         }
         __syncthreads();
         unsigned long long *t = src; src = dst; dst = t;
+    }
+    if (npass & 1) {                                      // an odd number of passes ends in the second buffer
+        for (int i = tid; i < K; i += K3_THREADS) a[i] = b2[i];
+        __syncthreads();
     }
 }
 
