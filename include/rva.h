@@ -325,6 +325,14 @@ int rva_conv1x1_head_f16(rva_ctx *ctx, const void *in, int ldi, const void *weig
 int rva_stem_conv_f16(rva_ctx *ctx, const void *in_planar, const void *weights, const float *bias,
                       void *out, int ldo, int batch, int H, int W, int Cout, rva_stream_t stream);
 
+/* rva_c2f_pair32_f16: one C2f bottleneck with 32 channels and a shortcut -- y = x + SiLU(conv3x3(SiLU(conv3x3(x)))) -- in one launch;
+ * replaces two session-internal Conv nodes + Add of the reference's ONNX graph (`session.run`, detector.py:597-609) and two
+ * rva_conv2d_nhwc_f16 launches of this library, bit-identical to them (same operations, same order); the 32-channel intermediate
+ * stays in LDS.  in / out: NHWC fp16 slices with row strides ldi / ldo (halfs, multiples of 8), 32 channels each, not overlapping;
+ * w1, w2: [64][9][32] fp16 as rva_conv2d_nhwc_f16 takes them (rows >= 32 unused), b1, b2: [64] fp32. */
+int rva_c2f_pair32_f16(rva_ctx *ctx, const void *in, int ldi, const void *w1, const float *b1, const void *w2, const float *b2, void *out,
+                       int ldo, int batch, int H, int W, rva_stream_t stream);
+
 /* rva_stem2_f16: the stem and the first downsampling convolution of YOLOv8s (3 -> 32 -> 64 channels, both 3x3 stride 2
  * pad 1 with bias + SiLU; ultralytics model.0 and model.1, reference call site detector.py:597-609 via the exported graph)
  * in ONE launch: the half-resolution 32-channel tensor stays in LDS.  in_planar, w1 ([64][32] fp16, column order of
@@ -376,6 +384,7 @@ int rva_yolo_head3_f16(rva_ctx *ctx, const void *const *box_logits, const int32_
  * -------------------------------------------------------------------------------------------- */
 #define RVA_PLAN_NO_STEM2 1   /* rva_yolov8_desc.flags: stem and first downsampling convolution as two launches (A/B switch) */
 #define RVA_PLAN_NO_CIN_PAD 2 /* ... convolutions with Cin % 32 != 0 keep their Cin (default: declared rounded up to 32, zero weights) */
+#define RVA_PLAN_NO_PAIR32 4  /* ... the 32-channel C2f bottlenecks (YOLOv8s at 160 x 160) as two convolution launches instead of rva_c2f_pair32_f16 */
 typedef struct rva_yolov8_plan rva_yolov8_plan;
 typedef struct rva_yolov8_desc {
     int32_t batch, height, width;     /* input tensor; height and width multiples of 32 */

@@ -57,6 +57,7 @@ class ConvWeights(C.Structure):
 
 RVA_PLAN_NO_STEM2 = 1
 RVA_PLAN_NO_CIN_PAD = 2
+RVA_PLAN_NO_PAIR32 = 4
 
 
 def _stale() -> bool:
@@ -165,6 +166,7 @@ def lib() -> C.CDLL:
         "rva_conv2d_nhwc_f16_v": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, C.c_int, _P, C.c_int] + [C.c_int] * 9 + [_P]),
         "rva_stem_conv_f16": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
         "rva_stem2_f16": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+        "rva_c2f_pair32_f16": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
         "rva_conv1x1_head_f16": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int,
                                            C.c_int, C.c_int, C.c_float, C.c_int, _P]),
         "rva_conv1x1_upcat_f16": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P, _P, _P, C.c_int, C.c_int, C.c_int,
@@ -209,7 +211,7 @@ EXPORTS = [
     "rva_tracker_snapshot_fetch", "rva_tracker_state",
     "rva_tracker_set_next_id", "rva_preview_nv12", "rva_decode_available", "rva_decoder_create", "rva_decoder_destroy", "rva_decoder_feed",
     "rva_decoder_next_frame", "rva_decoder_release", "rva_motion_nv12_batch", "rva_motion_nv12_masked_batch", "rva_motion_bgr_batch",
-    "rva_preprocess_nv12_masked_batch", "rva_resize_nv12_to_bgr_batch", "rva_tracker_set_box_scale", "rva_conv_cout_pad", "rva_conv_num_variants", "rva_conv2d_nhwc_f16", "rva_conv2d_nhwc_f16_v", "rva_stem_conv_f16", "rva_stem2_f16",
+    "rva_preprocess_nv12_masked_batch", "rva_resize_nv12_to_bgr_batch", "rva_tracker_set_box_scale", "rva_conv_cout_pad", "rva_conv_num_variants", "rva_conv2d_nhwc_f16", "rva_conv2d_nhwc_f16_v", "rva_stem_conv_f16", "rva_stem2_f16", "rva_c2f_pair32_f16",
     "rva_conv1x1_head_f16", "rva_conv1x1_upcat_f16", "rva_sppf_pool3_nhwc_f16", "rva_maxpool5_nhwc_f16", "rva_upsample2x_nhwc_f16", "rva_yolo_head_f16", "rva_yolo_head3_f16",
     "rva_yolov8_plan_create", "rva_yolov8_plan_destroy", "rva_yolov8_plan_info", "rva_yolov8_plan_run", "rva_yolov8_plan_run_lanes",
     "rva_yolov8_plan_run_range", "rva_yolov8_plan_tunable_desc", "rva_yolov8_plan_launch_tunable", "rva_yolov8_plan_set_variant",

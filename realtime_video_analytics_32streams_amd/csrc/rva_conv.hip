@@ -2733,6 +2733,183 @@ hipError_t launch_patch(S2Args &g, int num_cus, hipStream_t s)
 }
 
 // ---------------------------------------------------------------------------------------------------
+// The bottleneck of the first C2f of YOLOv8s -- y = x + SiLU(conv3x3(SiLU(conv3x3(x)))), 32 channels at 160 x 160 -- in ONE launch
+// (round 4).  Layer by layer the 160 x 160 stage is bandwidth-bound: the two patch launches move 122 MB each (patch halo included)
+// at what a device copy reaches.  Here the 32-channel intermediate never leaves LDS: per 4 x 32 output tile the (4 + 4) x 36 input
+// patch comes in once by LDS-DMA (pixels outside the image fetch a zero line: the first convolution's padding), the first
+// convolution runs over the (4 + 2) x 34 intermediate pixels the tile's outputs touch -- laid out with the INPUT patch's row pitch
+// (36), so that a fragment of 16 consecutive intermediate rows reads 16 consecutive input rows at a fixed offset per tap; two junk
+// columns per row are the price -- and writes them, SiLU applied and zero outside the image (the second convolution's padding), into
+// a second LDS image; the second convolution reads its taps from there, adds the shortcut from the centre of the input patch
+// and stores.  Reads 2.25 x 64 B + writes 64 B per output pixel instead of (1.33 + 1 + 1.33 + 1) x 64 B.  Same operations in the
+// same order as the two patch launches (taps in order, fp32 accumulation, bias, SiLU, one rounding; shortcut added to the rounded
+// value): bit-identical to them.  81 KB of LDS, two blocks per CU, four waves each.
+__device__ __attribute__((aligned(64))) unsigned g_zero_line[16];
+
+struct PairArgs {
+    const __half *in; int ldi;
+    const __half *w1; const float *b1; const __half *w2; const float *b2;
+    __half *out; int ldo;
+    int B, H, W, tiles_x, tiles_y, total;
+};
+constexpr int PR_TH = 4, PR_TW = 32, PR_PITCH = 36;
+constexpr int PR_IPIECES = 19;            // input patch rows: (TH + 4) x 36 = 288 (+ what the junk intermediate rows read: < 304)
+constexpr int PR_MFRAGS = 14;             // intermediate rows: (TH + 2) x 36 = 216 -> 14 fragments of 16
+constexpr int PR_SROW = 32 + 8;
+constexpr size_t PR_SMEM = (size_t)2 * 18 * 1024 + (size_t)PR_IPIECES * 1024 + (size_t)PR_MFRAGS * 1024 + (size_t)PR_TH * PR_TW * PR_SROW * 2;
+static_assert(2 * PR_SMEM <= 160 * 1024, "two blocks per CU");
+
+__global__ void __launch_bounds__(256) k_c2f_pair32(PairArgs a)
+{
+    constexpr int TH = PR_TH, TW = PR_TW, PITCH = PR_PITCH, NWV = 4, SROW = PR_SROW;
+    constexpr int NIP = (PR_IPIECES + NWV - 1) / NWV, NMF = (PR_MFRAGS + NWV - 1) / NWV;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __half *wl1 = (__half *)smem;                         // [9 taps][32][32], swizzled rows
+    __half *wl2 = wl1 + 18 * 512;
+    __half *inp = wl2 + 18 * 512;                         // [304][32]   row = py * 36 + px
+    __half *mid = inp + PR_IPIECES * 512;                 // [224][32]   row = my * 36 + mx
+    __half *stage = mid + PR_MFRAGS * 512;                // [128][SROW]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, q = lane >> 4, lrow = lane >> 2, lp = lane & 3;
+    const int tiles_img = a.tiles_x * a.tiles_y;
+    // both weight tensors, once per block (36 pieces)
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const int idx = wv + NWV * k, sub = idx % 18;
+        const int row = sub * 16 + lrow, tap = row >> 5, co = row & 31;
+        const __half *src = (idx < 18 ? a.w1 : a.w2) + (size_t)(co * 9 + tap) * 32 + ((lp - 2 * (row >> 2)) & 3) * 8;
+        __builtin_amdgcn_global_load_lds((glb_vptr)src, (lds_vptr)((idx < 18 ? wl1 : wl2) + sub * 512), 16, 0, 0);
+    }
+    float4 bv1[2], bv2[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        bv1[i] = *reinterpret_cast<const float4 *>(a.b1 + 16 * i + q * 4);
+        bv2[i] = *reinterpret_cast<const float4 *>(a.b2 + 16 * i + q * 4);
+    }
+    // the patch position of every input row this lane fills: the same for all tiles
+    int ppy[NIP], ppx[NIP], pc8[NIP];
+#pragma unroll
+    for (int k = 0; k < NIP; ++k) {
+        const int row = (wv + NWV * k) * 16 + lrow;
+        ppy[k] = row < (TH + 4) * PITCH ? row / PITCH : 1 << 20;          // rows behind the patch: never inside an image
+        ppx[k] = row % PITCH;
+        pc8[k] = ((lp - 2 * (row >> 2)) & 3) * 8;
+    }
+    // intermediate position of this lane's row in each of the wave's fragments
+    int mmy[NMF], mmx[NMF];
+#pragma unroll
+    for (int k = 0; k < NMF; ++k) {
+        const int row = (wv + NWV * k) * 16 + n;
+        mmy[k] = row / PITCH; mmx[k] = row % PITCH;
+    }
+    for (int t = blockIdx.x; t < a.total; t += gridDim.x) {
+        const int b = t / tiles_img, r2 = t - b * tiles_img, ty = r2 / a.tiles_x, tx = r2 - ty * a.tiles_x;
+        const int y0 = ty * TH, x0 = tx * TW;
+        // ---- the input patch: rows y0 - 2 .. y0 + TH + 1, columns x0 - 2 .. x0 + 33
+#pragma unroll
+        for (int k = 0; k < NIP; ++k) {
+            const int idx = wv + NWV * k;
+            if (idx < PR_IPIECES) {
+                const int iy = y0 - 2 + ppy[k], ix = x0 - 2 + ppx[k];
+                const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                const __half *src = ok ? a.in + ((size_t)(b * a.H + iy) * a.W + ix) * a.ldi + pc8[k] : reinterpret_cast<const __half *>(g_zero_line);
+                __builtin_amdgcn_global_load_lds((glb_vptr)src, (lds_vptr)(inp + idx * 512), 16, 0, 0);
+            }
+        }
+        wait_vm<0>();
+        __syncthreads();                                  // the patch (and, the first time, the weights) are in LDS
+        // ---- first convolution over the intermediate rows of this wave's fragments
+        f4 acc1[NMF][2];
+#pragma unroll
+        for (int k = 0; k < NMF; ++k) acc1[k][0] = acc1[k][1] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) {
+            const int toff = (tp / 3) * PITCH + tp % 3;
+            h8 af[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const h8 *>(wl1 + swz32(tp * 32 + 16 * i + n, q));
+#pragma unroll
+            for (int k = 0; k < NMF; ++k) {
+                if (wv + NWV * k < PR_MFRAGS) {
+                    const h8 bf = *reinterpret_cast<const h8 *>(inp + swz32((wv + NWV * k) * 16 + n + toff, q));
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) acc1[k][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf, acc1[k][i], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NMF; ++k) {
+            if (wv + NWV * k < PR_MFRAGS) {
+                const int row = (wv + NWV * k) * 16 + n;
+                const int iy = y0 - 1 + mmy[k], ix = x0 - 1 + mmx[k];
+                const bool inimg = mmx[k] < TW + 2 && mmy[k] < TH + 2 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const float4 bv = bv1[i];
+                    const float v0 = silu_f(acc1[k][i][0] + bv.x), v1 = silu_f(acc1[k][i][1] + bv.y), v2 = silu_f(acc1[k][i][2] + bv.z), v3 = silu_f(acc1[k][i][3] + bv.w);
+                    __half2 lo = __floats2half2_rn(v0, v1), hi = __floats2half2_rn(v2, v3);
+                    uint2 pk;
+                    pk.x = inimg ? *reinterpret_cast<uint32_t *>(&lo) : 0u;
+                    pk.y = inimg ? *reinterpret_cast<uint32_t *>(&hi) : 0u;
+                    *reinterpret_cast<uint2 *>(mid + swz32(row, 2 * i + (q >> 1)) + 4 * (q & 1)) = pk;
+                }
+            }
+        }
+        __syncthreads();                                  // the intermediate image is complete
+        // ---- second convolution: wave wv = output row wv, two fragments of 16 pixels
+        f4 acc2[2][2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc2[j][0] = acc2[j][1] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) {
+            const int rb = (wv + tp / 3) * PITCH + tp % 3 + n;
+            h8 af[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const h8 *>(wl2 + swz32(tp * 32 + 16 * i + n, q));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const h8 bf = *reinterpret_cast<const h8 *>(mid + swz32(rb + 16 * j, q));
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc2[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf, acc2[j][i], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float4 bv = bv2[i];
+                const float v0 = silu_f(acc2[j][i][0] + bv.x), v1 = silu_f(acc2[j][i][1] + bv.y), v2 = silu_f(acc2[j][i][2] + bv.z), v3 = silu_f(acc2[j][i][3] + bv.w);
+                __half2 lo = __floats2half2_rn(v0, v1), hi = __floats2half2_rn(v2, v3);
+                uint2 pk;
+                pk.x = *reinterpret_cast<uint32_t *>(&lo);
+                pk.y = *reinterpret_cast<uint32_t *>(&hi);
+                *reinterpret_cast<uint2 *>(stage + (size_t)(wv * TW + 16 * j + n) * SROW + 16 * i + q * 4) = pk;
+            }
+        __syncthreads();
+        // ---- + shortcut (the centre of the input patch), 16-byte row stores
+        for (int e = tid; e < TH * TW * 4; e += 256) {
+            const int px = e >> 2, pc = e & 3;
+            const int ry = px / TW, rx = px - ry * TW;
+            const int yy = y0 + ry, xx = x0 + rx;
+            if (yy < a.H && xx < a.W) {
+                uint4 v = *reinterpret_cast<const uint4 *>(stage + (size_t)px * SROW + pc * 8);
+                const uint4 r = *reinterpret_cast<const uint4 *>(inp + swz32((ry + 2) * PITCH + rx + 2, pc));
+                __half2 *vh = reinterpret_cast<__half2 *>(&v);
+                const __half2 *rh = reinterpret_cast<const __half2 *>(&r);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float2 x = __half22float2(vh[u]), y = __half22float2(rh[u]);
+                    vh[u] = __floats2half2_rn(x.x + y.x, x.y + y.y);
+                }
+                *reinterpret_cast<uint4 *>(a.out + ((size_t)(b * a.H + yy) * a.W + xx) * a.ldo + pc * 8) = v;
+            }
+        }
+        __syncthreads();                                  // patch and stage are free for the next tile
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Patch kernel, two wave sets half a tile period apart (3x3 stride 1, Cin = 64, Cout <= 64; weights resident in LDS).
 //
 // k_conv3_patch<1,64,64,8,1,2> runs its MFMA phase at 95 % of the matrix pipe's time, but per 16 x 32 tile that phase is
@@ -3727,6 +3904,28 @@ int rva_stem_conv_f16(rva_ctx *ctx, const void *in_planar, const void *weights, 
     if (grid > total_tiles) grid = total_tiles;
     if (W % 8 || ((uintptr_t)in_planar & 15)) return rva_fail(ctx, RVA_ERR_ARG, "rva_stem_conv_f16: W %% 8 == 0 and a 16-byte aligned input are required");
     k_stem<<<grid, 256, (size_t)(3 * 17 * 88 * 2) + (size_t)(256 * (Cout + 8 > LDSROW ? Cout + 8 : LDSROW) + 64 * LDSROW) * 2, (hipStream_t)stream_>>>(a, (const __half *)weights, bias);
+    RVA_HIP(ctx, hipGetLastError());
+    return RVA_OK;
+}
+
+int rva_c2f_pair32_f16(rva_ctx *ctx, const void *in, int ldi, const void *w1, const float *b1, const void *w2, const float *b2, void *out,
+                       int ldo, int batch, int H, int W, rva_stream_t stream_)
+{
+    if (!ctx || !in || !w1 || !b1 || !w2 || !b2 || !out || batch <= 0 || H <= 0 || W <= 0 || ldi % 8 || ldo % 8 || ldi < 32 || ldo < 32)
+        return rva_fail(ctx, RVA_ERR_ARG, "rva_c2f_pair32_f16: bad argument");
+    if ((size_t)batch * H * W >= (1ull << 31)) return rva_fail(ctx, RVA_ERR_ARG, "rva_c2f_pair32_f16: tensor too large");
+    if (!ctx->num_cus) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess) ctx->num_cus = prop.multiProcessorCount;
+        if (ctx->num_cus <= 0) ctx->num_cus = 256;
+    }
+    PairArgs a{(const __half *)in, ldi, (const __half *)w1, b1, (const __half *)w2, b2, (__half *)out, ldo, batch, H, W,
+               rva_ceil_div(W, PR_TW), rva_ceil_div(H, PR_TH), 0};
+    a.total = a.tiles_x * a.tiles_y * batch;
+    RVA_HIP(ctx, rva_func_smem((const void *)k_c2f_pair32, PR_SMEM));
+    int grid = 2 * ctx->num_cus;
+    if (grid > a.total) grid = a.total;
+    k_c2f_pair32<<<grid, 256, PR_SMEM, (hipStream_t)stream_>>>(a);
     RVA_HIP(ctx, hipGetLastError());
     return RVA_OK;
 }

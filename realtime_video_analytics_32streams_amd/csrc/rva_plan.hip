@@ -23,7 +23,7 @@
 
 namespace {
 
-enum StepKind { K_CONV, K_UPCAT, K_HEAD, K_STEM2, K_STEM, K_SPPF3, K_POOL5, K_UP2, K_HEAD3 };
+enum StepKind { K_CONV, K_UPCAT, K_HEAD, K_STEM2, K_STEM, K_SPPF3, K_POOL5, K_UP2, K_HEAD3, K_PAIR32 };
 
 struct View {           // a channel slice of an NHWC buffer
     char *base = nullptr; int ld = 0, off = 0, ch = 0;
@@ -200,6 +200,16 @@ struct Builder {
         for (int i = 0; i < n; ++i) {
             const rva_conv_weights *b1 = take(c, c, 3, 1, what), *b2 = take(c, c, 3, 1, what);
             View x = cat.sub((1 + i) * c, c);
+            if (c == 32 && shortcut && !(p->d.flags & RVA_PLAN_NO_PAIR32)) {
+                // both 3x3 convolutions and the shortcut in one launch, the intermediate in LDS (rva_c2f_pair32_f16)
+                Step s{}; s.kind = K_PAIR32;
+                int ci, co, kk, st;
+                if (!pack(&b1, 1, &s.w, &s.b, &ci, &co, &kk, &st) || !pack(&b2, 1, &s.w2, &s.b2, &ci, &co, &kk, &st)) return false;
+                View y = cat.sub((2 + i) * c, c);
+                s.in = x.ptr(); s.ldi = x.ld; s.out = y.ptr(); s.ldo = y.ld; s.H = h; s.W = w; s.Cin = s.Cout = c; s.k = 3; s.stride = 1; s.act = 1;
+                push(s, nullptr);
+                continue;
+            }
             if (!conv1(b1, x, tmp, h, w, 1)) return false;
             if (!conv1(b2, tmp, cat.sub((2 + i) * c, c), h, w, 1, shortcut ? &x : nullptr)) return false;
         }
@@ -363,6 +373,7 @@ int launch_step(rva_yolov8_plan *p, const Step &s, int variant, const void *inpu
     case K_CONV: return rva_conv2d_nhwc_f16_v(c, s.in, s.ldi, s.w, s.b, s.out, s.ldo, s.res, s.ldr, p->B, s.H, s.W, s.Cin, s.Cout, s.k, s.stride, s.act, variant, st);
     case K_UPCAT: return rva_conv1x1_upcat_f16(c, s.in, s.ldi, s.c_in, s.in2, s.ldi2, s.c_in2, s.w, s.b, s.out, s.ldo, p->B, s.H, s.W, s.Cout, s.act, variant, st);
     case K_HEAD: return rva_conv1x1_head_f16(c, s.in, s.ldi, s.w, s.b, p->B, s.H, s.W, s.Cin, s.Cout, s.mode, output, p->nc, p->A, s.a0, s.stride_px, variant, st);
+    case K_PAIR32: return rva_c2f_pair32_f16(c, s.in, s.ldi, s.w, s.b, s.w2, s.b2, s.out, s.ldo, p->B, s.H, s.W, st);
     case K_STEM2: return rva_stem2_f16(c, input, s.w, s.b, s.w2, s.b2, s.out, s.ldo, p->B, s.H, s.W, st);
     case K_STEM: return rva_stem_conv_f16(c, input, s.w, s.b, s.out, s.ldo, p->B, s.H, s.W, s.Cout, st);
     case K_SPPF3: return rva_sppf_pool3_nhwc_f16(c, s.in, s.ldi, s.out, s.out2, s.out3, s.ldo, p->B, s.H, s.W, s.Cin, st);

@@ -17,6 +17,7 @@ test is unchanged.  No host synchronisation and no allocation after construction
 from __future__ import annotations
 
 import ctypes as C
+import os
 import time
 from typing import Dict, List, Optional, Tuple
 
@@ -110,7 +111,8 @@ class FusedYoloV8:
         assert len(net.h15.m) == len(net.h18.m) == len(net.h21.m) == d.depth_head
         d.nc, d.reg_max, d.n_convs = net.nc, net.detect.reg_max, len(convs)
         d.flags = (N.RVA_PLAN_NO_STEM2 if os.environ.get("RVA_NO_STEM2", "0") == "1" else 0) | \
-                  (N.RVA_PLAN_NO_CIN_PAD if os.environ.get("RVA_NO_CIN_PAD", "0") == "1" else 0)
+                  (N.RVA_PLAN_NO_CIN_PAD if os.environ.get("RVA_NO_CIN_PAD", "0") == "1" else 0) | \
+                  (0 if self._use_pair32() else N.RVA_PLAN_NO_PAIR32)
         h = C.c_void_p()
         with torch.cuda.device(self.dev):
             self.ctx.check(self.L.rva_yolov8_plan_create(self.ctx.handle, C.byref(d), arr, C.byref(h)), "rva_yolov8_plan_create")
@@ -399,6 +401,19 @@ class FusedYoloV8:
             self._outs[index] = torch.empty_like(self._outs[0])
         self.out = self._outs[index]
         return self.out
+
+    def _use_pair32(self) -> bool:
+        """The 32-channel C2f bottleneck (YOLOv8s at 160 x 160) as ONE launch with the intermediate in LDS (rva_c2f_pair32_f16) or as
+        two convolution launches.  Fused, a forward pass alone is 2.2 % shorter (1.749 against 1.787 ms, bit-identical output) -- less
+        memory traffic in a bandwidth-bound stage -- but it recomputes the intermediate's halo (+30 % SiLUs and MFMAs in that stage),
+        and with four forward passes side by side, where instruction issue and not bandwidth is what is short, the pipeline loses
+        0.5 % (22.36-22.41 k against 22.47-22.55 k frames/s, same box, three alternating pairs).  So: fused for a plan that serves one
+        tick at a time (tune_overlap <= 1: `TickPipeline.tick()`, the per-frame API, depth-1 runners), two launches for a plan that
+        serves overlapping ticks.  ``RVA_PAIR32=1 / 0`` forces either."""
+        env = os.environ.get("RVA_PAIR32")
+        if env in ("0", "1"):
+            return env == "1"
+        return int(os.environ.get("RVA_TUNE_LAYER_OVERLAP", self.tune_overlap)) <= 1
 
     @property
     def n_launches(self) -> int:

@@ -192,6 +192,48 @@ def test_fused_stem_and_first_downsampling_conv(shape):
     assert float((diff > 0).float().mean()) < 0.05
 
 
+@pytest.mark.parametrize("shape", [(2, 160, 160), (3, 37, 50), (1, 4, 32), (5, 9, 7)])
+def test_fused_bottleneck_pair_equals_two_convolution_launches(shape):
+    """rva_c2f_pair32_f16 (y = x + SiLU(conv3x3(SiLU(conv3x3(x)))), 32 channels, the intermediate in LDS) against the two launches it
+    replaces -- the patch kernel (variant 45) for both convolutions, the shortcut as the second one's residual --: BIT-IDENTICAL (same
+    operations in the same order), on slices of a wider concat buffer as the plan uses it, ragged tiles, images smaller than a tile;
+    and against the fp32 reference within the per-layer bound."""
+    B, H, W = shape
+    g = torch.Generator().manual_seed(5 + H)
+    cat = (torch.randn((B, H, W, 96), generator=g) * 0.5).half().cuda()          # [y0 | x = y1 | y2]: the C2f concat buffer at c = 32
+    w1 = (torch.randn((32, 32, 3, 3), generator=g) / 288 ** 0.5).half()
+    w2 = (torch.randn((32, 32, 3, 3), generator=g) / 288 ** 0.5).half()
+    b1, b2 = torch.randn((32,), generator=g) * 0.1, torch.randn((32,), generator=g) * 0.1
+    L, ctx = N.lib(), ops.context()
+    cpad = L.rva_conv_cout_pad(32)
+    def packed(w, b):
+        wp = torch.zeros((cpad, 9, 32), dtype=torch.float16); wp[:32] = w.permute(0, 2, 3, 1).reshape(32, 9, 32)
+        bp = torch.zeros(cpad); bp[:32] = b
+        return wp.cuda(), bp.cuda()
+    wp1, bp1 = packed(w1, b1)
+    wp2, bp2 = packed(w2, b2)
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    x_ptr, y_ptr = cat.data_ptr() + 2 * 32, cat.data_ptr() + 2 * 64
+    # two launches
+    ref = cat.clone()
+    tmp = torch.zeros((B, H, W, 32), dtype=torch.float16, device="cuda")
+    rx, ry = ref.data_ptr() + 2 * 32, ref.data_ptr() + 2 * 64
+    ctx.check(L.rva_conv2d_nhwc_f16_v(ctx.handle, C.c_void_p(rx), 96, C.c_void_p(wp1.data_ptr()), C.c_void_p(bp1.data_ptr()), C.c_void_p(tmp.data_ptr()), 32,
+                                      None, 0, B, H, W, 32, 32, 3, 1, 1, 45, s), "conv 1")
+    ctx.check(L.rva_conv2d_nhwc_f16_v(ctx.handle, C.c_void_p(tmp.data_ptr()), 32, C.c_void_p(wp2.data_ptr()), C.c_void_p(bp2.data_ptr()), C.c_void_p(ry), 96,
+                                      C.c_void_p(rx), 96, B, H, W, 32, 32, 3, 1, 1, 45, s), "conv 2")
+    # one launch
+    ctx.check(L.rva_c2f_pair32_f16(ctx.handle, C.c_void_p(x_ptr), 96, C.c_void_p(wp1.data_ptr()), C.c_void_p(bp1.data_ptr()), C.c_void_p(wp2.data_ptr()),
+                                   C.c_void_p(bp2.data_ptr()), C.c_void_p(y_ptr), 96, B, H, W, s), "pair")
+    torch.cuda.synchronize()
+    assert torch.equal(cat[..., :64], ref[..., :64])                              # the other slices are untouched
+    assert torch.equal(cat[..., 64:], ref[..., 64:]), float((cat[..., 64:].float() - ref[..., 64:].float()).abs().max())
+    x = ref[..., 32:64]
+    t = _conv_ref(x, w1.cuda(), b1.cuda(), 3, 1, 1, None).half()
+    want = _conv_ref(t, w2.cuda(), b2.cuda(), 3, 1, 1, x)
+    _assert_conv_close(cat[..., 64:].float(), want, x)
+
+
 def test_pool_upsample_head_primitives():
     L, ctx = N.lib(), ops.context()
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -426,7 +468,7 @@ def test_c_plan_through_the_abi_alone():
     ctx.check(L.rva_yolov8_plan_create(ctx.handle, C.byref(d), arr, C.byref(plan)), "rva_yolov8_plan_create")
     info = [C.c_int32() for _ in range(5)]
     ctx.check(L.rva_yolov8_plan_info(plan, *[C.byref(v) for v in info]), "info")
-    assert info[0].value == 8400 and info[1].value == 84 and info[2].value == 60 and info[3].value == 58
+    assert info[0].value == 8400 and info[1].value == 84 and info[2].value == 59 and info[3].value == 56      # steps / tunable steps (the 32-channel bottleneck is one fixed launch)
     x = torch.rand((2, 3, 640, 640), device="cuda").half()
     out = torch.zeros((2, 84, 8400), dtype=torch.float16, device="cuda")
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
