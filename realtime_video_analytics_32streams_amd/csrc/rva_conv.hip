@@ -3913,6 +3913,7 @@ int rva_c2f_pair32_f16(rva_ctx *ctx, const void *in, int ldi, const void *w1, co
 {
     if (!ctx || !in || !w1 || !b1 || !w2 || !b2 || !out || batch <= 0 || H <= 0 || W <= 0 || ldi % 8 || ldo % 8 || ldi < 32 || ldo < 32)
         return rva_fail(ctx, RVA_ERR_ARG, "rva_c2f_pair32_f16: bad argument");
+    if ((((size_t)in) | ((size_t)out) | ((size_t)w1) | ((size_t)w2)) & 15) return rva_fail(ctx, RVA_ERR_ARG, "rva_c2f_pair32_f16: 16-byte aligned tensors");
     if ((size_t)batch * H * W >= (1ull << 31)) return rva_fail(ctx, RVA_ERR_ARG, "rva_c2f_pair32_f16: tensor too large");
     if (!ctx->num_cus) {
         hipDeviceProp_t prop;
