@@ -467,6 +467,7 @@ def main():
                 # taken right behind the timed region, before the other legs allocate and free gigabytes of scratch --, and (below)
                 # the deployment itself: one tick per 33.33 ms from a host timer on an otherwise idle GPU
                 out["long_run"] = long_run_leg(runner, S, lat if K >= 300 else None, elapsed if K >= 300 else None)
+                out["power_clock"] = power_leg(runner, S)
             extras(args, out, sources[:S], rctx, dev, dcfg, tcfg)
             if world == 1:
                 if K < 300:     # the headline percentile is a percentile: taken from the >= 300-tick leg, the short region's kept beside it
@@ -549,6 +550,51 @@ def long_run_leg(runner, S, lat=None, elapsed=None, K=320):
     return {"ticks": int(K), "frame_latency_samples": int(K * S), "ticks_in_flight": runner.depth,
             "frames_per_s": round(S * K / elapsed, 1), **_percentiles(lat),
             "source": "the timed region itself" if reused else f"{K} further saturated ticks after the timed region (same runner)"}
+
+
+def _smi_sample():
+    """Package power (W) and shader clock (MHz) from rocm-smi, or None (the tool's JSON keys differ between releases: matched loosely)."""
+    import re
+    import subprocess
+    try:
+        p = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=15)
+        cards = json.loads(p.stdout)
+        card = cards.get("card0") or next(iter(cards.values()))
+        power = next((float(v) for k, v in card.items() if "ower" in k and "(W)" in k), None)
+        sclk = next((int(re.search(r"(\d+)\s*Mhz", str(v), re.I).group(1)) for k, v in card.items() if k.lower().startswith("sclk") and re.search(r"\d+\s*Mhz", str(v), re.I)), None)
+        return None if power is None and sclk is None else {"package_power_w": power, "sclk_mhz": sclk}
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def power_leg(runner, S, seconds=3.0):
+    """What the GPU draws and clocks at while the pipeline is saturated: ~3 s of further saturated ticks on the same runner, rocm-smi
+    sampled from a host thread after 1 s and 2 s (an instantaneous reading each).  DESIGN.md section 9 (1b): four ticks in flight run at
+    the package power limit."""
+    import threading
+    samples = []
+
+    def sampler():
+        for _ in range(2):
+            time.sleep(1.0)
+            smp = _smi_sample()
+            if smp:
+                samples.append(smp)
+    th = threading.Thread(target=sampler, daemon=True)
+    torch.cuda.synchronize()
+    th.start()
+    t0 = time.perf_counter()
+    n = inflight = 0
+    while time.perf_counter() - t0 < seconds:
+        if inflight == runner.depth:
+            runner.collect(); inflight -= 1
+        runner.submit(); inflight += 1; n += 1
+    while inflight:
+        runner.collect(); inflight -= 1
+    elapsed = time.perf_counter() - t0
+    th.join(timeout=20)
+    return {"ticks": n, "frames_per_s": round(S * n / elapsed, 1), "ticks_in_flight": runner.depth, "samples": samples,
+            "what": "rocm-smi --showpower --showclocks while the saturated pipeline runs (two instantaneous readings)"}
 
 
 def paced_leg(args, det, sources, streams, tcfg, saturated_fps, ticks=300, period=1.0 / 30.0):
