@@ -468,6 +468,10 @@ def main():
                 # the deployment itself: one tick per 33.33 ms from a host timer on an otherwise idle GPU
                 out["long_run"] = long_run_leg(runner, S, lat if K >= 300 else None, elapsed if K >= 300 else None)
                 out["power_clock"] = power_leg(runner, S)
+                clk = [x["sclk_mhz"] for x in out["power_clock"]["samples"] if x.get("sclk_mhz")]
+                if clk:     # the dense peak is quoted at 2400 MHz; under the package power limit the chip holds less
+                    out["power_clock"]["detector_frac_of_mfma_peak_at_sampled_clock"] = round(
+                        out["detector_frac_of_mfma_peak_in_pipeline"] * 2400.0 / (sum(clk) / len(clk)), 4)
             extras(args, out, sources[:S], rctx, dev, dcfg, tcfg)
             if world == 1:
                 if K < 300:     # the headline percentile is a percentile: taken from the >= 300-tick leg, the short region's kept beside it
